@@ -1,0 +1,200 @@
+/*
+ * mirt.h -- C ABI of the MI355X trace path ("mirt" = MI ray trace).
+ *
+ * The library replaces the body of the reference's createRender() between scene load and PNG save:
+ * the per-pixel loop RayTracer/main.cpp:137-163 and everything it calls (computePixelColor
+ * main.cpp:176-201, calculateLightingColor main.cpp:203-268, Scene::findClosestIntersection
+ * Scene.cpp:299-301 -> Partition.cpp:31-53 -> Partition.h:28-39, AABB::intersect AABB.cpp:49-78,
+ * Triangle::intersect Triangle.cpp:147-175, Sphere::intersect Sphere.cpp:59-87,
+ * Camera::createRayToPixel / createPointFromRay Camera.cpp:15-28, Color quantisation Color.cpp:13-23).
+ *
+ * The host keeps the reference's scene parser, transform stack and Partition tree builder; it hands this
+ * library a FLATTENED copy of the constructed Scene (plain arrays, no pointers into the Scene survive
+ * mirt_scene_create) and receives the B,G,R byte buffer that Renderer::createImage (Renderer.h:9) takes.
+ *
+ * Conventions: every function returns 0 on success and a negative MIRT_E_* code on failure, never throws
+ * and never calls exit(); the message for the calling thread's last failure is mirt_last_error().
+ * A mirt_scene handle belongs to one device and must not be used from two host threads at once.
+ * All floating point is IEEE binary32; matrices are column-major (GLM order: m[col*4+row]).
+ */
+#ifndef MIRT_H
+#define MIRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIRT_OK 0
+#define MIRT_E_INVALID (-1)  /* bad argument / inconsistent scene description */
+#define MIRT_E_DEVICE (-2)   /* HIP runtime error (message holds hipGetErrorString) */
+#define MIRT_E_NOMEM (-3)    /* host or device allocation failed */
+
+/* ---- flattened Partition tree (Partition.h:16-43) ------------------------------------------------
+ * Nodes are emitted in depth-first pre-order, left subtree first, so the order of the leaf ranges in
+ * leaf_prims[] is the order in which Partition::intersect (Partition.cpp:42-43) visits leaves.
+ *   interior: a = index of the left child or MIRT_NO_CHILD, b = index of the right child or MIRT_NO_CHILD
+ *             (Partition::split deletes an empty child, Partition.cpp:90-97)
+ *   leaf:     a = first entry in leaf_prims[], b = MIRT_LEAF_FLAG | entry count (0 is legal)
+ * bmin/bmax are AABB::min / AABB::max of PartitionNode::box. */
+#define MIRT_NO_CHILD 0x7fffffffu
+#define MIRT_LEAF_FLAG 0x80000000u
+typedef struct mirt_node {
+	float bmin[3];
+	uint32_t a;
+	float bmax[3];
+	uint32_t b;
+} mirt_node;
+
+/* Sphere.h:19-21 + Shape::transform (Shape.h:25).  Minv = glm::inverse(M), computed by the host with the
+ * same GLM the reference uses so that it is the matrix Sphere::intersect recomputes on every call
+ * (Sphere.cpp:60,79). */
+typedef struct mirt_sphere {
+	float center[3];
+	float radius;
+	float M[16];
+	float Minv[16];
+} mirt_sphere;
+
+/* Material (SceneObjects.hpp:16-22), Color channels as raw floats (Color.h:19). */
+typedef struct mirt_material {
+	float diffuse[3];
+	float specular[3];
+	float emission[3];
+	float ambient[3];
+	float shininess;
+} mirt_material;
+
+/* Light (SceneObjects.hpp:24-29): location.w > 0 means point light, else directional. */
+typedef struct mirt_light {
+	float location[4];
+	float color[3];
+	float pad;
+} mirt_light;
+
+/* Camera fields (Camera.h:15-20) as the Camera object holds them: up is already normalised by the
+ * Camera constructor (Camera.cpp:4); forward = look_at - look_from is recomputed by the library. */
+typedef struct mirt_camera {
+	float look_from[3];
+	float look_at[3];
+	float up[3];
+	float fovy_deg;
+} mirt_camera;
+
+/* Everything createRender reads from a loaded Scene (Scene.h:13-48).  Primitive ids are indices into
+ * Scene::getSceneObjects() (parse order); triangles and spheres live in separate arrays and carry
+ * their primitive id.  Triangle vertices are world space (Triangle.cpp:22-25), 9 floats per triangle:
+ * v1.xyz v2.xyz v3.xyz. */
+typedef struct mirt_scene_desc {
+	uint32_t struct_size; /* = sizeof(mirt_scene_desc) */
+	uint32_t n_nodes;
+	const mirt_node* nodes;
+	uint32_t n_leaf_prims;
+	const uint32_t* leaf_prims; /* primitive ids, leaf by leaf, each leaf in PartitionNode::objects order */
+	uint32_t n_prims;
+	uint32_t n_triangles;
+	const float* tri_verts;
+	const uint32_t* tri_prim;
+	uint32_t n_spheres;
+	uint32_t n_materials;
+	const mirt_sphere* spheres;
+	const uint32_t* sphere_prim;
+	const uint32_t* prim_material; /* n_prims indices into materials[] */
+	const mirt_material* materials;
+	uint32_t n_lights;
+	int32_t max_depth; /* Scene::maxDepth (Scene.cpp:11,131) */
+	const mirt_light* lights; /* file order; lights are not transformed (Scene.cpp:39-52) */
+	mirt_camera camera;
+	float attenuation[3]; /* Scene::attenuation (Scene.cpp:10,56) */
+} mirt_scene_desc;
+
+/* Feature bits = enum class Feature (main.cpp:35-42); debug views = enum class Debug (main.cpp:24-33). */
+#define MIRT_F_DIFFUSE 1u
+#define MIRT_F_SPECULAR 2u
+#define MIRT_F_SHADOWS 4u
+#define MIRT_F_REFLECTIONS 8u
+#define MIRT_F_ALL 15u
+#define MIRT_DEBUG_DIFFUSE_INTENSITY 0u
+#define MIRT_DEBUG_SPECULAR_INTENSITY 1u
+#define MIRT_DEBUG_NORMAL_MAP 2u
+#define MIRT_DEBUG_SHADOW_MAP 3u
+#define MIRT_DEBUG_PRIMARY_MAP 4u
+#define MIRT_DEBUG_LIGHT_DIRECTION_MAP 5u
+#define MIRT_DEBUG_NONE 6u
+
+/* Arithmetic mode of the traversal and primitive tests.
+ *   EXACT: every operation of AABB.cpp:53-72, Triangle.cpp:148-167 and Sphere.cpp:60-82 is evaluated in the
+ *          reference's order with IEEE division and square root and no fused multiply-add.
+ *   FAST:  reciprocal-multiply slab test and Moller-Trumbore triangle test with the reference's 1e-4
+ *          thresholds; hit distances differ from the reference in the last bits. */
+#define MIRT_TRACE_EXACT 0u
+#define MIRT_TRACE_FAST 1u
+
+/* One image, or one rank's share of it.  The image is cut into tile_w x tile_h tiles numbered row-major;
+ * tile k is rendered iff k % tile_stride == first_tile.  tile_stride == 1 renders the whole image. */
+typedef struct mirt_render_params {
+	uint32_t struct_size; /* = sizeof(mirt_render_params) */
+	uint32_t width, height; /* Scene::getWidth/getHeight (main.cpp:120-121) */
+	uint32_t feature_bits;  /* replaces the global featureFlags (main.cpp:91) */
+	uint32_t debug_mode;    /* replaces the global debugFlag (main.cpp:92) */
+	uint32_t trace_mode;
+	uint32_t tile_w, tile_h; /* 0,0 = library default */
+	uint32_t first_tile, tile_stride;
+} mirt_render_params;
+
+/* Ray counts follow the reference's control flow: primary = pixels; shadow = one per light per hit at every
+ * depth (main.cpp:208-223); reflection = one per hit at depth d < maxDepth when REFLECTIONS is on (main.cpp:177,190).
+ * *_traced are the rays the device really traced (a reflection ray whose weight mat.specular is 0 in all
+ * channels, and shadow rays whose contribution is multiplied by zero, may be skipped). */
+typedef struct mirt_stats {
+	uint64_t primary_rays, shadow_rays, reflection_rays;
+	uint64_t shadow_rays_traced, reflection_rays_traced;
+	uint64_t primary_hits;
+	float device_ms; /* HIP-event time of the last mirt_render call, all kernels, excluding the copy back */
+	float pad;
+} mirt_stats;
+
+typedef struct mirt_scene mirt_scene;
+
+/* Upload a deep copy of the scene to `device` (hipSetDevice ordinal).  Replaces nothing in the reference;
+ * it is the hand-over point after `Scene scene(path)` (main.cpp:107). */
+int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out);
+void mirt_scene_destroy(mirt_scene* scene);
+
+/* Replaces the pixel loop main.cpp:137-157: fills bgr_out[3*(i*width+j)+{0,1,2}] = B,G,R for every pixel of
+ * the tiles selected by params; bytes of other tiles are left untouched.  bgr_out is host memory of
+ * width*height*3 bytes, top row first -- exactly what Renderer::createImage(BYTE*, std::string) takes
+ * (Renderer.h:9, Renderer.cpp:13).  Synchronous.  stats may be NULL. */
+int mirt_render(mirt_scene* scene, const mirt_render_params* params, uint8_t* bgr_out, mirt_stats* stats);
+
+/* Same work, asynchronous, output left in device memory.  d_out receives the selected tiles packed one
+ * after another in increasing tile number, each tile tile_w*tile_h pixels row-major inside the tile, 3 bytes
+ * B,G,R per pixel, edge tiles padded to full size (mirt_tile_buffer_bytes gives the size).  With
+ * tile_stride == 1 and tile_w == 0 the layout is the plain width*height*3 image instead.  hip_stream is a
+ * hipStream_t (NULL = default stream).  No host synchronisation happens inside the call. */
+int mirt_render_device(mirt_scene* scene, const mirt_render_params* params, void* d_out, size_t d_out_bytes, void* hip_stream);
+size_t mirt_tile_buffer_bytes(const mirt_render_params* params);
+/* Counters of the most recent mirt_render_device call on this scene (synchronises hip_stream). */
+int mirt_get_stats(mirt_scene* scene, void* hip_stream, mirt_stats* stats);
+
+/* Reassemble an image from `n_ranks` packed tile buffers laid back to back in d_tiles (rank r's buffer at
+ * r * per_rank_bytes, rendered with first_tile = r, tile_stride = n_ranks) into d_bgr (width*height*3).
+ * The step after the RCCL gather; has no counterpart in the single-threaded reference. */
+int mirt_assemble_tiles(int device, const mirt_render_params* params, uint32_t n_ranks, const void* d_tiles, size_t per_rank_bytes, void* d_bgr, void* hip_stream);
+
+/* Narrow seam: Intersection Scene::findClosestIntersection(const Ray&) const (Scene.h:37) for n rays given as
+ * host arrays of 3 floats.  prim_id_out[k] = primitive id or -1, dist_out[k] = Intersection::distAlongRay
+ * (+inf on a miss), normal_out (may be NULL) = Intersection::intersectNormal. */
+int mirt_trace_rays(mirt_scene* scene, uint32_t trace_mode, uint64_t n, const float* origins, const float* dirs, int32_t* prim_id_out, float* dist_out, float* normal_out);
+
+/* Parity hook: nearest hit of every primary ray (Camera::createRayToPixel(j+0.5, i+0.5), main.cpp:152). */
+int mirt_trace_primary_ids(mirt_scene* scene, uint32_t trace_mode, uint32_t width, uint32_t height, int32_t* prim_id_out, float* dist_out);
+
+const char* mirt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRT_H */
