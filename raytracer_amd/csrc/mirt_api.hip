@@ -1,0 +1,615 @@
+// C ABI of the trace path (include/mirt.h): scene upload, frame orchestration, parity hooks.
+// Host code here only re-packs data and launches kernels; all tracing arithmetic lives in mirt_kernels.hip.
+#include "../../include/mirt.h"
+#include "mirt_kernels.hip"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	g_err = buf;
+	return code;
+}
+
+#define HIPCHK(expr)                                                                                          \
+	do {                                                                                                      \
+		hipError_t e_ = (expr);                                                                               \
+		if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? MIRT_E_NOMEM : MIRT_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+	} while (0)
+
+struct DevBuf {
+	void* p = nullptr;
+	size_t bytes = 0;
+	int ensure(size_t need) {
+		if (need <= bytes) return MIRT_OK;
+		if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+		HIPCHK(hipMalloc(&p, need));
+		bytes = need;
+		return MIRT_OK;
+	}
+	void release() {
+		if (p) (void)hipFree(p);
+		p = nullptr;
+		bytes = 0;
+	}
+};
+
+struct Workspace {
+	DevBuf rayO, rayD, hitO, hitD, hitN, hit0, litL, litS, depthCnt, counters, out;
+	void release() {
+		rayO.release(); rayD.release(); hitO.release(); hitD.release(); hitN.release(); hit0.release();
+		litL.release(); litS.release(); depthCnt.release(); counters.release(); out.release();
+	}
+};
+
+// host-side float helpers, same formulas as the device ones (GLM 0.9.8.5 scalar code)
+struct h3 { float x, y, z; };
+inline h3 H3(float x, float y, float z) { h3 r = {x, y, z}; return r; }
+inline h3 hsub(h3 a, h3 b) { return H3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline float hdot(h3 a, h3 b) { float x = a.x * b.x, y = a.y * b.y, z = a.z * b.z; return x + y + z; }
+inline h3 hcross(h3 a, h3 b) { return H3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+inline h3 hnorm(h3 a) { float s = 1.0f / sqrtf(hdot(a, a)); return H3(a.x * s, a.y * s, a.z * s); }
+
+}  // namespace
+
+struct mirt_scene {
+	int device = 0;
+	int numCUs = 256;
+	DScene ds;
+	DevBuf nodes, leafs, tris, spheres, materials, lights;
+	Workspace ws;
+	hipStream_t stream = nullptr; // used by the synchronous entry points
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	uint32_t nLights = 0;
+	int32_t maxDepth = 0;
+	uint32_t wideDepth = 0;
+	// last asynchronous frame, for mirt_get_stats
+	uint64_t lastPrimary = 0;
+	uint32_t lastFeatures = 0;
+	bool lastValid = false;
+};
+
+namespace {
+
+// ---- re-pack the flattened Partition tree into wide nodes ----------------------------------------------------------
+struct Packer {
+	const mirt_scene_desc* d;
+	std::vector<float> wide;         // 16 floats per wide node
+	std::vector<uint32_t> leafPos;   // flat node index -> position in the leaf stream
+	std::vector<uint32_t> stream;    // count-prefixed leaf lists
+	std::vector<int64_t> primSlot;   // prim id -> tri index, or -1 - sphere index, or INT64_MIN
+	uint32_t maxDepth = 0;
+	bool bad = false;
+
+	static bool isLeaf(const mirt_node& n) { return (n.b & MIRT_LEAF_FLAG) != 0; }
+	static bool inside(const mirt_node& c, const mirt_node& p) {
+		for (int k = 0; k < 3; ++k)
+			if (!(c.bmin[k] >= p.bmin[k] && c.bmax[k] <= p.bmax[k])) return false;
+		return true;
+	}
+	// follow chains of single-child interior nodes whose child box is nested in the parent box
+	uint32_t skipChain(uint32_t i) const {
+		for (;;) {
+			const mirt_node& n = d->nodes[i];
+			if (isLeaf(n)) return i;
+			const bool hasL = n.a != MIRT_NO_CHILD, hasR = n.b != MIRT_NO_CHILD;
+			if (hasL == hasR) return i;
+			const uint32_t c = hasL ? n.a : n.b;
+			if (!inside(d->nodes[c], n)) return i;
+			i = c;
+		}
+	}
+	uint32_t refOf(uint32_t flatIdx, uint32_t depth) {
+		const mirt_node& n = d->nodes[flatIdx];
+		if (isLeaf(n)) return REF_LEAF | leafPos[flatIdx];
+		return emit(flatIdx, depth);
+	}
+	uint32_t emit(uint32_t flatIdx, uint32_t depth) {
+		if (depth > maxDepth) maxDepth = depth;
+		if (depth > 4000) { bad = true; return REF_NONE; }
+		const uint32_t me = (uint32_t)(wide.size() / 16);
+		wide.resize(wide.size() + 16, 0.0f);
+		const mirt_node n = d->nodes[flatIdx];
+		uint32_t refs[2] = {REF_NONE, REF_NONE};
+		const uint32_t ch[2] = {n.a, n.b};
+		float boxes[2][6];
+		for (int s = 0; s < 2; ++s) {
+			for (int k = 0; k < 6; ++k) boxes[s][k] = 0.0f;
+			if (ch[s] == MIRT_NO_CHILD) continue;
+			const uint32_t c = skipChain(ch[s]);
+			const mirt_node& cn = d->nodes[c];
+			for (int k = 0; k < 3; ++k) { boxes[s][k] = cn.bmin[k]; boxes[s][3 + k] = cn.bmax[k]; }
+			refs[s] = refOf(c, depth + 1);
+		}
+		float* w = wide.data() + (size_t)me * 16;
+		memcpy(w + 0, boxes[0], 12); memcpy(w + 3, &refs[0], 4);
+		memcpy(w + 4, boxes[0] + 3, 12); memcpy(w + 7, &refs[1], 4);
+		memcpy(w + 8, boxes[1], 12);
+		memcpy(w + 12, boxes[1] + 3, 12);
+		return me;
+	}
+};
+
+int validate_desc(const mirt_scene_desc* d) {
+	if (!d) return fail(MIRT_E_INVALID, "scene description is NULL");
+	if (d->struct_size != sizeof(mirt_scene_desc)) return fail(MIRT_E_INVALID, "mirt_scene_desc.struct_size %u != %zu", d->struct_size, sizeof(mirt_scene_desc));
+	if (d->n_nodes && !d->nodes) return fail(MIRT_E_INVALID, "nodes is NULL");
+	if (d->n_leaf_prims && !d->leaf_prims) return fail(MIRT_E_INVALID, "leaf_prims is NULL");
+	if (d->n_triangles && (!d->tri_verts || !d->tri_prim)) return fail(MIRT_E_INVALID, "triangle arrays are NULL");
+	if (d->n_spheres && (!d->spheres || !d->sphere_prim)) return fail(MIRT_E_INVALID, "sphere arrays are NULL");
+	if (d->n_prims && (!d->prim_material || !d->materials)) return fail(MIRT_E_INVALID, "material arrays are NULL");
+	if (d->n_lights && !d->lights) return fail(MIRT_E_INVALID, "lights is NULL");
+	if (d->max_depth > MIRT_MAX_DEPTH_LIMIT) return fail(MIRT_E_INVALID, "max_depth %d exceeds the supported %d", d->max_depth, MIRT_MAX_DEPTH_LIMIT);
+	if (d->n_nodes >= 0x7fffffffu || d->n_leaf_prims >= 0x70000000u) return fail(MIRT_E_INVALID, "tree too large for 31-bit references");
+	for (uint32_t i = 0; i < d->n_nodes; ++i) {
+		const mirt_node& n = d->nodes[i];
+		if (n.b & MIRT_LEAF_FLAG) {
+			const uint64_t cnt = n.b & ~MIRT_LEAF_FLAG;
+			if ((uint64_t)n.a + cnt > d->n_leaf_prims) return fail(MIRT_E_INVALID, "leaf %u: range [%u,+%llu) outside leaf_prims", i, n.a, (unsigned long long)cnt);
+		}
+		else {
+			// pre-order: children come after their parent, which also rules out cycles
+			if (n.a != MIRT_NO_CHILD && (n.a <= i || n.a >= d->n_nodes)) return fail(MIRT_E_INVALID, "node %u: bad left child %u", i, n.a);
+			if (n.b != MIRT_NO_CHILD && (n.b <= i || n.b >= d->n_nodes)) return fail(MIRT_E_INVALID, "node %u: bad right child %u", i, n.b);
+			if (n.a == MIRT_NO_CHILD && n.b == MIRT_NO_CHILD) return fail(MIRT_E_INVALID, "node %u: interior node without children", i);
+		}
+	}
+	for (uint32_t i = 0; i < d->n_leaf_prims; ++i)
+		if (d->leaf_prims[i] >= d->n_prims) return fail(MIRT_E_INVALID, "leaf_prims[%u] = %u outside the %u scene objects", i, d->leaf_prims[i], d->n_prims);
+	for (uint32_t i = 0; i < d->n_triangles; ++i)
+		if (d->tri_prim[i] >= d->n_prims) return fail(MIRT_E_INVALID, "tri_prim[%u] out of range", i);
+	for (uint32_t i = 0; i < d->n_spheres; ++i)
+		if (d->sphere_prim[i] >= d->n_prims) return fail(MIRT_E_INVALID, "sphere_prim[%u] out of range", i);
+	for (uint32_t i = 0; i < d->n_prims; ++i)
+		if (d->prim_material[i] >= d->n_materials) return fail(MIRT_E_INVALID, "prim_material[%u] out of range", i);
+	return MIRT_OK;
+}
+
+int upload(DevBuf& b, const void* src, size_t bytes) {
+	int e = b.ensure(bytes ? bytes : 16);
+	if (e) return e;
+	if (bytes) HIPCHK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+	return MIRT_OK;
+}
+
+int check_params(const mirt_scene* s, const mirt_render_params* p, uint32_t& tileW, uint32_t& tileH) {
+	if (!s) return fail(MIRT_E_INVALID, "scene handle is NULL");
+	if (!p) return fail(MIRT_E_INVALID, "render params are NULL");
+	if (p->struct_size != sizeof(mirt_render_params)) return fail(MIRT_E_INVALID, "mirt_render_params.struct_size %u != %zu", p->struct_size, sizeof(mirt_render_params));
+	if (p->width == 0 || p->height == 0 || p->width > 65536 || p->height > 65536) return fail(MIRT_E_INVALID, "image size %ux%u not supported", p->width, p->height);
+	if (p->debug_mode > MIRT_DEBUG_NONE) return fail(MIRT_E_INVALID, "debug_mode %u unknown", p->debug_mode);
+	if (p->trace_mode > MIRT_TRACE_FAST) return fail(MIRT_E_INVALID, "trace_mode %u unknown", p->trace_mode);
+	tileW = p->tile_w ? p->tile_w : 32;
+	tileH = p->tile_h ? p->tile_h : 32;
+	if ((tileW & 7) || (tileH & 7) || tileW > 1024 || tileH > 1024) return fail(MIRT_E_INVALID, "tile size %ux%u must be multiples of 8, at most 1024", tileW, tileH);
+	if (p->tile_stride == 0 || p->first_tile >= p->tile_stride) return fail(MIRT_E_INVALID, "first_tile %u / tile_stride %u invalid", p->first_tile, p->tile_stride);
+	return MIRT_OK;
+}
+
+struct TileGeom {
+	uint32_t tileW, tileH, tilesX, tilesY, nLocal;
+	uint64_t nSlots, livePixels;
+};
+
+TileGeom tile_geom(const mirt_render_params* p, uint32_t tileW, uint32_t tileH) {
+	TileGeom g;
+	g.tileW = tileW; g.tileH = tileH;
+	g.tilesX = (p->width + tileW - 1) / tileW;
+	g.tilesY = (p->height + tileH - 1) / tileH;
+	const uint64_t total = (uint64_t)g.tilesX * g.tilesY;
+	g.nLocal = total > p->first_tile ? (uint32_t)((total - p->first_tile + p->tile_stride - 1) / p->tile_stride) : 0;
+	g.nSlots = (uint64_t)g.nLocal * tileW * tileH;
+	g.livePixels = 0;
+	for (uint32_t lt = 0; lt < g.nLocal; ++lt) {
+		const uint64_t k = p->first_tile + (uint64_t)lt * p->tile_stride;
+		const uint32_t tx = (uint32_t)(k % g.tilesX), ty = (uint32_t)(k / g.tilesX);
+		const uint32_t w = (tx + 1) * tileW <= p->width ? tileW : p->width - tx * tileW;
+		const uint32_t h = (ty + 1) * tileH <= p->height ? tileH : p->height - ty * tileH;
+		g.livePixels += (uint64_t)w * h;
+	}
+	return g;
+}
+
+bool packed_layout(const mirt_render_params* p) { return !(p->tile_stride == 1 && p->tile_w == 0 && p->tile_h == 0); }
+
+template <int MODE>
+void launch_frame(mirt_scene* s, const DFrame& F, uint8_t* out, hipStream_t st) {
+	const int grid = s->numCUs * 8;
+	int launch = 0;
+	hipLaunchKernelGGL(k_primary<MODE>, dim3(grid), dim3(BLOCK), 0, st, s->ds, F, out, launch++);
+	if (F.debug != D_PRIMARY_MAP) {
+		const int last = (F.features & F_REFLECTIONS) ? s->maxDepth : 0;
+		for (int depth = 0; depth <= last; ++depth) {
+			if (depth > 0) hipLaunchKernelGGL(k_trace<MODE>, dim3(grid), dim3(BLOCK), 0, st, s->ds, F, depth, launch++);
+			hipLaunchKernelGGL(k_shade<MODE>, dim3(grid), dim3(BLOCK), 0, st, s->ds, F, depth, launch++);
+		}
+		hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(BLOCK), 0, st, F, out);
+	}
+}
+
+int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t d_out_bytes, hipStream_t st, bool packed) {
+	uint32_t tileW, tileH;
+	int e = check_params(s, p, tileW, tileH);
+	if (e) return e;
+	if (!d_out) return fail(MIRT_E_INVALID, "output buffer is NULL");
+	const TileGeom g = tile_geom(p, tileW, tileH);
+	const size_t need = packed ? (size_t)g.nSlots * 3 : (size_t)p->width * p->height * 3;
+	if (d_out_bytes < need) return fail(MIRT_E_INVALID, "output buffer holds %zu bytes, %zu needed", d_out_bytes, need);
+	if (g.nSlots >= 0xffffffc0ull) return fail(MIRT_E_INVALID, "too many pixel slots for one launch");
+	HIPCHK(hipSetDevice(s->device));
+	s->lastValid = false;
+	if (g.nSlots == 0) { s->lastPrimary = 0; s->lastFeatures = p->feature_bits; return MIRT_OK; }
+	if (s->maxDepth < 0) {
+		// depth 0 already exceeds maxDepth: computePixelColor returns Color() for every pixel (main.cpp:177,199)
+		HIPCHK(hipMemsetAsync(d_out, 0, need, st));
+		return MIRT_OK;
+	}
+	Workspace& w = s->ws;
+	const size_t n = (size_t)g.nSlots;
+	const size_t depths = (size_t)s->maxDepth + 1;
+	if ((e = w.rayO.ensure(2 * n * 16))) return e;
+	if ((e = w.rayD.ensure(2 * n * 16))) return e;
+	if ((e = w.hitO.ensure(n * 16))) return e;
+	if ((e = w.hitD.ensure(n * 16))) return e;
+	if ((e = w.hitN.ensure(n * 16))) return e;
+	if ((e = w.hit0.ensure(n * 4))) return e;
+	if ((e = w.litL.ensure(depths * n * 16))) return e;
+	if ((e = w.litS.ensure(depths * n * 16))) return e;
+	if ((e = w.depthCnt.ensure(n))) return e;
+	if ((e = w.counters.ensure(CTR_COUNT * 4))) return e;
+	DFrame F;
+	F.rayO = (float4*)w.rayO.p; F.rayD = (float4*)w.rayD.p;
+	F.hitO = (float4*)w.hitO.p; F.hitD = (float4*)w.hitD.p; F.hitN = (float4*)w.hitN.p;
+	F.hit0 = (uint32_t*)w.hit0.p;
+	F.litL = (float4*)w.litL.p; F.litS = (float4*)w.litS.p;
+	F.depthCnt = (uint8_t*)w.depthCnt.p;
+	F.counters = (uint32_t*)w.counters.p;
+	F.nSlots = (uint32_t)g.nSlots;
+	F.width = p->width; F.height = p->height;
+	F.tileW = tileW; F.tileH = tileH; F.tilesX = g.tilesX; F.nTilesLocal = g.nLocal;
+	F.firstTile = p->first_tile; F.tileStride = p->tile_stride;
+	F.features = p->feature_bits; F.debug = p->debug_mode;
+	F.packedTiles = packed ? 1u : 0u;
+	HIPCHK(hipEventRecord(s->ev0, st));
+	HIPCHK(hipMemsetAsync(w.counters.p, 0, CTR_COUNT * 4, st));
+	if (p->trace_mode == MIRT_TRACE_FAST) launch_frame<MODE_FAST>(s, F, (uint8_t*)d_out, st);
+	else launch_frame<MODE_EXACT>(s, F, (uint8_t*)d_out, st);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(s->ev1, st));
+	s->lastPrimary = g.livePixels;
+	s->lastFeatures = p->feature_bits;
+	s->lastValid = true;
+	return MIRT_OK;
+}
+
+int read_stats(mirt_scene* s, hipStream_t st, mirt_stats* out) {
+	memset(out, 0, sizeof *out);
+	HIPCHK(hipStreamSynchronize(st));
+	out->primary_rays = s->lastPrimary;
+	if (!s->lastValid) return MIRT_OK;
+	uint32_t c[CTR_COUNT];
+	HIPCHK(hipMemcpy(c, s->ws.counters.p, sizeof c, hipMemcpyDeviceToHost));
+	uint64_t hits = 0, refl = 0;
+	for (int d = 0; d <= s->maxDepth; ++d) hits += c[CTR_NHITS(d)];
+	for (int d = 1; d <= s->maxDepth; ++d) refl += c[CTR_NRAYS(d)];
+	out->primary_hits = c[CTR_NHITS(0)];
+	out->shadow_rays = hits * s->nLights; // main.cpp:208-223: one query per light per hit, whatever the feature bits
+	out->shadow_rays_traced = (s->lastFeatures & MIRT_F_SHADOWS) ? out->shadow_rays : 0;
+	out->reflection_rays = out->reflection_rays_traced = refl;
+	float ms = 0.0f;
+	HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+	out->device_ms = ms;
+	return MIRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mirt_last_error(void) { return g_err.c_str(); }
+
+int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
+	if (!out) return fail(MIRT_E_INVALID, "out is NULL");
+	*out = nullptr;
+	int e = validate_desc(d);
+	if (e) return e;
+	HIPCHK(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	HIPCHK(hipGetDeviceProperties(&prop, device));
+
+	Packer pk;
+	pk.d = d;
+	// primitive id -> typed reference
+	pk.primSlot.assign(d->n_prims, INT64_MIN);
+	for (uint32_t i = 0; i < d->n_triangles; ++i) pk.primSlot[d->tri_prim[i]] = (int64_t)i;
+	for (uint32_t i = 0; i < d->n_spheres; ++i) pk.primSlot[d->sphere_prim[i]] = -1 - (int64_t)i;
+	// leaf stream in node (= depth-first) order; objects that are neither triangle nor sphere never hit
+	// (Shape::intersect, Shape.cpp:44-46) and are dropped
+	pk.leafPos.assign(d->n_nodes, 0);
+	for (uint32_t i = 0; i < d->n_nodes; ++i) {
+		const mirt_node& n = d->nodes[i];
+		if (!(n.b & MIRT_LEAF_FLAG)) continue;
+		pk.leafPos[i] = (uint32_t)pk.stream.size();
+		const uint32_t cnt = n.b & ~MIRT_LEAF_FLAG;
+		const size_t at = pk.stream.size();
+		pk.stream.push_back(0);
+		uint32_t kept = 0;
+		for (uint32_t k = 0; k < cnt; ++k) {
+			const int64_t sl = pk.primSlot[d->leaf_prims[n.a + k]];
+			if (sl == INT64_MIN) continue;
+			pk.stream.push_back(sl >= 0 ? (uint32_t)sl : (PRIM_SPHERE | (uint32_t)(-1 - sl)));
+			++kept;
+		}
+		pk.stream[at] = kept;
+	}
+	if (pk.stream.size() >= 0x7fffffffull) return fail(MIRT_E_INVALID, "leaf stream too long");
+
+	mirt_scene* s = new (std::nothrow) mirt_scene();
+	if (!s) return fail(MIRT_E_NOMEM, "out of host memory");
+	s->device = device;
+	s->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	memset(&s->ds, 0, sizeof s->ds);
+	DScene& ds = s->ds;
+	ds.rootRef = REF_NONE;
+	for (int k = 0; k < 3; ++k) { ds.rootMin[k] = 0.0f; ds.rootMax[k] = -1.0f; } // misses every ray when there is no tree
+	if (d->n_nodes) {
+		const uint32_t r = pk.skipChain(0);
+		const mirt_node& rn = d->nodes[r];
+		for (int k = 0; k < 3; ++k) { ds.rootMin[k] = rn.bmin[k]; ds.rootMax[k] = rn.bmax[k]; }
+		ds.rootRef = pk.refOf(r, 0);
+		if (pk.bad || pk.maxDepth + 2 > STACK_MAX) {
+			delete s;
+			return fail(MIRT_E_INVALID, "Partition tree depth %u exceeds the traversal stack (%d)", pk.maxDepth, STACK_MAX);
+		}
+	}
+	s->wideDepth = pk.maxDepth;
+
+	// triangles: { N, dot(v1,N) } { v1, area } { v2, prim } { v3, material }
+	std::vector<float> tris((size_t)d->n_triangles * 16);
+	for (uint32_t i = 0; i < d->n_triangles; ++i) {
+		const float* v = d->tri_verts + (size_t)i * 9;
+		const h3 v1 = H3(v[0], v[1], v[2]), v2 = H3(v[3], v[4], v[5]), v3 = H3(v[6], v[7], v[8]);
+		const h3 N = hnorm(hcross(hsub(v2, v1), hsub(v3, v1)));      // Triangle.cpp:173-175
+		const float dv = hdot(v1, N);                                // Triangle.cpp:153
+		const h3 e1 = hsub(v3, v2), e2 = hsub(v1, v3);               // Triangle.cpp:148-149
+		const float area = hdot(hcross(e1, e2), N) / 2.0f;           // Triangle.cpp:162
+		float* t = tris.data() + (size_t)i * 16;
+		t[0] = N.x; t[1] = N.y; t[2] = N.z; t[3] = dv;
+		t[4] = v1.x; t[5] = v1.y; t[6] = v1.z; t[7] = area;
+		t[8] = v2.x; t[9] = v2.y; t[10] = v2.z; memcpy(t + 11, &d->tri_prim[i], 4);
+		t[12] = v3.x; t[13] = v3.y; t[14] = v3.z; memcpy(t + 15, &d->prim_material[d->tri_prim[i]], 4);
+	}
+	// spheres: { c, powf(r,2) } M[4] Minv[4] { prim, material, r, 0 }
+	std::vector<float> sph((size_t)d->n_spheres * 40);
+	for (uint32_t i = 0; i < d->n_spheres; ++i) {
+		const mirt_sphere& sp = d->spheres[i];
+		float* t = sph.data() + (size_t)i * 40;
+		t[0] = sp.center[0]; t[1] = sp.center[1]; t[2] = sp.center[2];
+		t[3] = powf(sp.radius, 2.0f);                                // Sphere.cpp:64 glm::pow(float,float)
+		memcpy(t + 4, sp.M, 64);
+		memcpy(t + 20, sp.Minv, 64);
+		memcpy(t + 36, &d->sphere_prim[i], 4);
+		memcpy(t + 37, &d->prim_material[d->sphere_prim[i]], 4);
+		t[38] = sp.radius; t[39] = 0.0f;
+	}
+	std::vector<float> mats((size_t)d->n_materials * 16, 0.0f);
+	for (uint32_t i = 0; i < d->n_materials; ++i) {
+		const mirt_material& m = d->materials[i];
+		float* t = mats.data() + (size_t)i * 16;
+		t[0] = m.diffuse[0]; t[1] = m.diffuse[1]; t[2] = m.diffuse[2]; t[3] = m.shininess;
+		t[4] = m.specular[0]; t[5] = m.specular[1]; t[6] = m.specular[2];
+		t[8] = m.emission[0]; t[9] = m.emission[1]; t[10] = m.emission[2];
+		t[12] = m.ambient[0]; t[13] = m.ambient[1]; t[14] = m.ambient[2];
+	}
+	std::vector<float> lights((size_t)d->n_lights * 8, 0.0f);
+	for (uint32_t i = 0; i < d->n_lights; ++i) {
+		const mirt_light& l = d->lights[i];
+		float* t = lights.data() + (size_t)i * 8;
+		memcpy(t, l.location, 16);
+		memcpy(t + 4, l.color, 12);
+	}
+	// camera basis (Camera.cpp:4-7,16-19): identical for every pixel, so evaluated once here
+	{
+		const mirt_camera& c = d->camera;
+		const h3 from = H3(c.look_from[0], c.look_from[1], c.look_from[2]);
+		const h3 at = H3(c.look_at[0], c.look_at[1], c.look_at[2]);
+		const h3 up = H3(c.up[0], c.up[1], c.up[2]);
+		const h3 fwd = hsub(at, from);
+		const h3 nf = hnorm(fwd);
+		const h3 w = H3(-nf.x, -nf.y, -nf.z);
+		const h3 u = hnorm(hcross(up, w));
+		const h3 v = hnorm(hcross(w, u));
+		ds.cam.eye[0] = from.x; ds.cam.eye[1] = from.y; ds.cam.eye[2] = from.z;
+		ds.cam.u[0] = u.x; ds.cam.u[1] = u.y; ds.cam.u[2] = u.z;
+		ds.cam.v[0] = v.x; ds.cam.v[1] = v.y; ds.cam.v[2] = v.z;
+		ds.cam.w[0] = w.x; ds.cam.w[1] = w.y; ds.cam.w[2] = w.z;
+		const float rad = (c.fovy_deg / 2.0f) * 0.01745329251994329576923690768489f; // glm::radians
+		ds.cam.tanHalf = tanf(rad);
+	}
+	ds.nLights = d->n_lights;
+	ds.maxDepth = d->max_depth;
+	for (int k = 0; k < 3; ++k) ds.atten[k] = d->attenuation[k];
+	s->nLights = d->n_lights;
+	s->maxDepth = d->max_depth;
+
+	e = upload(s->nodes, pk.wide.data(), pk.wide.size() * 4);
+	if (!e) e = upload(s->leafs, pk.stream.data(), pk.stream.size() * 4);
+	if (!e) e = upload(s->tris, tris.data(), tris.size() * 4);
+	if (!e) e = upload(s->spheres, sph.data(), sph.size() * 4);
+	if (!e) e = upload(s->materials, mats.data(), mats.size() * 4);
+	if (!e) e = upload(s->lights, lights.data(), lights.size() * 4);
+	if (!e && hipStreamCreate(&s->stream) != hipSuccess) e = fail(MIRT_E_DEVICE, "hipStreamCreate failed");
+	if (!e && (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess)) e = fail(MIRT_E_DEVICE, "hipEventCreate failed");
+	if (e) {
+		std::string keep = g_err;
+		mirt_scene_destroy(s);
+		g_err = keep;
+		return e;
+	}
+	ds.nodes = (const float4*)s->nodes.p;
+	ds.leafs = (const uint32_t*)s->leafs.p;
+	ds.tris = (const float4*)s->tris.p;
+	ds.spheres = (const float4*)s->spheres.p;
+	ds.materials = (const float4*)s->materials.p;
+	ds.lights = (const float4*)s->lights.p;
+	*out = s;
+	return MIRT_OK;
+}
+
+void mirt_scene_destroy(mirt_scene* s) {
+	if (!s) return;
+	(void)hipSetDevice(s->device);
+	if (s->stream) (void)hipStreamSynchronize(s->stream);
+	s->nodes.release(); s->leafs.release(); s->tris.release(); s->spheres.release(); s->materials.release(); s->lights.release();
+	s->ws.release();
+	if (s->ev0) (void)hipEventDestroy(s->ev0);
+	if (s->ev1) (void)hipEventDestroy(s->ev1);
+	if (s->stream) (void)hipStreamDestroy(s->stream);
+	delete s;
+}
+
+size_t mirt_tile_buffer_bytes(const mirt_render_params* p) {
+	if (!p || p->tile_stride == 0 || p->first_tile >= p->tile_stride) return 0;
+	if (!packed_layout(p)) return (size_t)p->width * p->height * 3;
+	const uint32_t tw = p->tile_w ? p->tile_w : 32, th = p->tile_h ? p->tile_h : 32;
+	// every rank's buffer has the size of rank 0's (the largest), so gathered buffers are equally spaced
+	mirt_render_params q = *p;
+	q.first_tile = 0;
+	return (size_t)tile_geom(&q, tw, th).nSlots * 3;
+}
+
+int mirt_render_device(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t d_out_bytes, void* hip_stream) {
+	if (!p) return fail(MIRT_E_INVALID, "render params are NULL");
+	return render_async(s, p, d_out, d_out_bytes, (hipStream_t)hip_stream, packed_layout(p));
+}
+
+int mirt_get_stats(mirt_scene* s, void* hip_stream, mirt_stats* stats) {
+	if (!s || !stats) return fail(MIRT_E_INVALID, "NULL argument");
+	HIPCHK(hipSetDevice(s->device));
+	return read_stats(s, (hipStream_t)hip_stream, stats);
+}
+
+int mirt_render(mirt_scene* s, const mirt_render_params* p, uint8_t* bgr_out, mirt_stats* stats) {
+	uint32_t tileW, tileH;
+	int e = check_params(s, p, tileW, tileH);
+	if (e) return e;
+	if (!bgr_out) return fail(MIRT_E_INVALID, "bgr_out is NULL");
+	HIPCHK(hipSetDevice(s->device));
+	const bool whole = p->tile_stride == 1;
+	const TileGeom g = tile_geom(p, tileW, tileH);
+	const size_t bytes = whole ? (size_t)p->width * p->height * 3 : (size_t)g.nSlots * 3;
+	if (bytes == 0) { if (stats) memset(stats, 0, sizeof *stats); return MIRT_OK; }
+	if ((e = s->ws.out.ensure(bytes))) return e;
+	if ((e = render_async(s, p, s->ws.out.p, bytes, s->stream, !whole))) return e;
+	if (whole) {
+		HIPCHK(hipMemcpyAsync(bgr_out, s->ws.out.p, bytes, hipMemcpyDeviceToHost, s->stream));
+		HIPCHK(hipStreamSynchronize(s->stream));
+	}
+	else {
+		std::vector<uint8_t> tmp(bytes);
+		HIPCHK(hipMemcpyAsync(tmp.data(), s->ws.out.p, bytes, hipMemcpyDeviceToHost, s->stream));
+		HIPCHK(hipStreamSynchronize(s->stream));
+		for (uint32_t lt = 0; lt < g.nLocal; ++lt) {
+			const uint64_t k = p->first_tile + (uint64_t)lt * p->tile_stride;
+			const uint32_t x0 = (uint32_t)(k % g.tilesX) * tileW, y0 = (uint32_t)(k / g.tilesX) * tileH;
+			for (uint32_t y = 0; y < tileH && y0 + y < p->height; ++y) {
+				const uint32_t wpx = x0 + tileW <= p->width ? tileW : p->width - x0;
+				memcpy(bgr_out + ((size_t)(y0 + y) * p->width + x0) * 3, tmp.data() + ((size_t)lt * tileW * tileH + (size_t)y * tileW) * 3, (size_t)wpx * 3);
+			}
+		}
+	}
+	if (stats) return read_stats(s, s->stream, stats);
+	return MIRT_OK;
+}
+
+int mirt_assemble_tiles(int device, const mirt_render_params* p, uint32_t n_ranks, const void* d_tiles, size_t per_rank_bytes, void* d_bgr, void* hip_stream) {
+	if (!p || !d_tiles || !d_bgr || n_ranks == 0) return fail(MIRT_E_INVALID, "NULL or zero argument");
+	const uint32_t tw = p->tile_w ? p->tile_w : 32, th = p->tile_h ? p->tile_h : 32;
+	if ((tw & 7) || (th & 7)) return fail(MIRT_E_INVALID, "tile size must be multiples of 8");
+	mirt_render_params q = *p;
+	q.first_tile = 0;
+	q.tile_stride = n_ranks;
+	const TileGeom g = tile_geom(&q, tw, th);
+	if (per_rank_bytes < (size_t)g.nSlots * 3) return fail(MIRT_E_INVALID, "per_rank_bytes %zu smaller than a rank's tile buffer %zu", per_rank_bytes, (size_t)g.nSlots * 3);
+	HIPCHK(hipSetDevice(device));
+	const uint64_t n = (uint64_t)p->width * p->height;
+	const int grid = (int)((n + BLOCK - 1) / BLOCK < 8192 ? (n + BLOCK - 1) / BLOCK : 8192);
+	hipLaunchKernelGGL(k_assemble, dim3(grid), dim3(BLOCK), 0, (hipStream_t)hip_stream, p->width, p->height, tw, th, g.tilesX, n_ranks,
+	                   (const uint8_t*)d_tiles, per_rank_bytes, (uint8_t*)d_bgr);
+	HIPCHK(hipGetLastError());
+	return MIRT_OK;
+}
+
+int mirt_trace_rays(mirt_scene* s, uint32_t trace_mode, uint64_t n, const float* origins, const float* dirs, int32_t* prim_id_out, float* dist_out, float* normal_out) {
+	if (!s) return fail(MIRT_E_INVALID, "scene handle is NULL");
+	if (trace_mode > MIRT_TRACE_FAST) return fail(MIRT_E_INVALID, "trace_mode %u unknown", trace_mode);
+	if (n == 0) return MIRT_OK;
+	if (!origins || !dirs || !prim_id_out || !dist_out) return fail(MIRT_E_INVALID, "NULL ray or result array");
+	HIPCHK(hipSetDevice(s->device));
+	DevBuf o, d, id, dist, nrm;
+	int e = 0;
+	if (!e) e = upload(o, origins, n * 12);
+	if (!e) e = upload(d, dirs, n * 12);
+	if (!e) e = id.ensure(n * 4);
+	if (!e) e = dist.ensure(n * 4);
+	if (!e && normal_out) e = nrm.ensure(n * 12);
+	if (!e) {
+		const int grid = (int)((n + BLOCK - 1) / BLOCK < (uint64_t)s->numCUs * 8 ? (n + BLOCK - 1) / BLOCK : (uint64_t)s->numCUs * 8);
+		if (trace_mode == MIRT_TRACE_FAST)
+			hipLaunchKernelGGL(k_trace_list<MODE_FAST>, dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, n, (const float*)o.p, (const float*)d.p, (int32_t*)id.p, (float*)dist.p, (float*)nrm.p);
+		else
+			hipLaunchKernelGGL(k_trace_list<MODE_EXACT>, dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, n, (const float*)o.p, (const float*)d.p, (int32_t*)id.p, (float*)dist.p, (float*)nrm.p);
+		hipError_t he = hipGetLastError();
+		if (he == hipSuccess) he = hipStreamSynchronize(s->stream);
+		if (he == hipSuccess) he = hipMemcpy(prim_id_out, id.p, n * 4, hipMemcpyDeviceToHost);
+		if (he == hipSuccess) he = hipMemcpy(dist_out, dist.p, n * 4, hipMemcpyDeviceToHost);
+		if (he == hipSuccess && normal_out) he = hipMemcpy(normal_out, nrm.p, n * 12, hipMemcpyDeviceToHost);
+		if (he != hipSuccess) e = fail(MIRT_E_DEVICE, "mirt_trace_rays: %s", hipGetErrorString(he));
+	}
+	o.release(); d.release(); id.release(); dist.release(); nrm.release();
+	return e;
+}
+
+int mirt_trace_primary_ids(mirt_scene* s, uint32_t trace_mode, uint32_t width, uint32_t height, int32_t* prim_id_out, float* dist_out) {
+	if (!s) return fail(MIRT_E_INVALID, "scene handle is NULL");
+	if (trace_mode > MIRT_TRACE_FAST) return fail(MIRT_E_INVALID, "trace_mode %u unknown", trace_mode);
+	if (!prim_id_out || !dist_out || width == 0 || height == 0) return fail(MIRT_E_INVALID, "NULL result array or empty image");
+	HIPCHK(hipSetDevice(s->device));
+	const uint64_t n = (uint64_t)width * height;
+	DevBuf id, dist;
+	int e = id.ensure(n * 4);
+	if (!e) e = dist.ensure(n * 4);
+	if (!e) {
+		const int grid = (int)((n + BLOCK - 1) / BLOCK < (uint64_t)s->numCUs * 8 ? (n + BLOCK - 1) / BLOCK : (uint64_t)s->numCUs * 8);
+		if (trace_mode == MIRT_TRACE_FAST)
+			hipLaunchKernelGGL(k_primary_ids<MODE_FAST>, dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, width, height, (int32_t*)id.p, (float*)dist.p);
+		else
+			hipLaunchKernelGGL(k_primary_ids<MODE_EXACT>, dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, width, height, (int32_t*)id.p, (float*)dist.p);
+		hipError_t he = hipGetLastError();
+		if (he == hipSuccess) he = hipStreamSynchronize(s->stream);
+		if (he == hipSuccess) he = hipMemcpy(prim_id_out, id.p, n * 4, hipMemcpyDeviceToHost);
+		if (he == hipSuccess) he = hipMemcpy(dist_out, dist.p, n * 4, hipMemcpyDeviceToHost);
+		if (he != hipSuccess) e = fail(MIRT_E_DEVICE, "mirt_trace_primary_ids: %s", hipGetErrorString(he));
+	}
+	id.release(); dist.release();
+	return e;
+}
+
+}  // extern "C"

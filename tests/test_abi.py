@@ -1,0 +1,43 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mirt.h declares (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+from conftest import ROOT
+from raytracer_amd import _capi
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _capi.load_library()
+    header = open(os.path.join(ROOT, "include", "mirt.h")).read()
+    declared = set(re.findall(r"\b(mirt_[a-z_]+)\s*\(", header))
+    bound = {name for name, _, _ in _capi.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_struct_sizes_match_header_layout():
+    assert C.sizeof(_capi.Node) == 32
+    assert C.sizeof(_capi.Sphere) == 144
+    assert C.sizeof(_capi.Material) == 52
+    assert C.sizeof(_capi.Light) == 32
+    assert C.sizeof(_capi.Camera) == 40
+    assert C.sizeof(_capi.RenderParams) == 40
+    assert C.sizeof(_capi.Stats) == 56
+
+
+def test_invalid_arguments_are_rejected_without_a_device():
+    lib = _capi.load_library()
+    h = C.c_void_p()
+    assert lib.mirt_scene_create(None, 0, C.byref(h)) == -1
+    assert b"NULL" in lib.mirt_last_error()
+    d = _capi.SceneDesc()
+    d.struct_size = 3
+    assert lib.mirt_scene_create(C.byref(d), 0, C.byref(h)) == -1
+    assert b"struct_size" in lib.mirt_last_error()
+    p = _capi.make_params(64, 64, tile_w=32, tile_h=32, first_tile=1, tile_stride=4)
+    # 2x2 tiles of 32x32 over 4 ranks: every rank's buffer is sized like rank 0's
+    assert lib.mirt_tile_buffer_bytes(C.byref(p)) == 32 * 32 * 3
+    p0 = _capi.make_params(100, 50)
+    assert lib.mirt_tile_buffer_bytes(C.byref(p0)) == 100 * 50 * 3
