@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (primary + shadow + reflection) of the trace path on the Stanford Dragon scene.
+
+  python bench.py --gpus 1 --steps K --warmup W          Dragon 3840x2160, maxdepth 5, all features, one MI355X
+  torchrun ... bench.py --gpus N ...                       Dragon 7680x4320 cut into interleaved tiles over N GPUs,
+                                                           RCCL gather of the tile buffers + reassembly on rank 0
+
+A step is one frame: every kernel of the path (primary, per-depth trace/shade, resolve) over the whole image, scene and
+framebuffer resident in HBM.  Rank 0 prints ONE JSON line.  Rays are counted the way the reference's control flow spawns
+them (RayTracer/main.cpp:176-223): primary = pixels, shadow = lights x hits at every depth, reflection = hits at depth
+d < maxdepth.
+
+The `cpu_baseline` leg (rank 0, N = 1 only) times the reference's own compiled classes (oracle/_ref, kind "reference")
+or, if that build is absent, the C restatement (kind "port") on a bounded row sample of the same image, one thread.
+The `roofline` object prices the frame against HBM bandwidth with ALGORITHMIC bytes: the reference's exhaustive tree
+walk's box tests x 32 B + primitive tests x 40 B (112+4 for spheres) + 32 B ray state, per ray kind, measured by the
+oracle's visit counters on the same row sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0
+NODE_BYTES, TRI_BYTES, SPHERE_BYTES, RAY_STATE_BYTES = 32, 40, 116, 32
+DRAGON = os.path.join(ROOT, "tests", "golden", "scene7.flat.npz")
+DRAGON_SCENE_FILE = os.path.join(ROOT, "tests", "golden", "scenes", "scene7.test")
+
+
+def cpu_baseline_and_visits(flat, width, height, row_step):
+    """Oracle leg: (cpu_baseline dict, visits[3][3], sample ray counts[3]).  Only the checker is timed here."""
+    from oracle.bind import CPort, RefOracle, REF_LIB
+    port = CPort(flat)
+    t0 = time.perf_counter()
+    _, st = port.render_rows(width, height, 0, height, row_step=row_step)
+    t_port = time.perf_counter() - t0
+    rays = [st["primary_rays"], st["shadow_rays"], st["reflection_rays"]]
+    sample = "every %dth row of %dx%d (%d rays), 1 thread" % (row_step, width, height, sum(rays))
+    base = {"value": sum(rays) / t_port / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port", "sample": sample + ", C restatement with visit counters on"}
+    if os.path.exists(REF_LIB) and os.path.exists(DRAGON_SCENE_FILE):
+        import tempfile
+        lines = open(DRAGON_SCENE_FILE).read().split("\n")
+        lines = ["size %d %d" % (width, height) if ln.strip().startswith("size ") else ln for ln in lines]
+        with tempfile.NamedTemporaryFile("w", suffix=".test", delete=False) as f:
+            f.write("\n".join(lines))
+        try:
+            ref = RefOracle(f.name)  # the reference's own parser + Partition build
+            _, rs = ref.render(width, height, row_step=row_step)
+            ref.close()
+        finally:
+            os.unlink(f.name)
+        n = rs["primary"] + rs["shadow"] + rs["reflection"]
+        assert [rs["primary"], rs["shadow"], rs["reflection"]] == rays, "reference and restatement disagree on ray counts"
+        base = {"value": n / rs["seconds"] / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference",
+                "sample": sample + "; reference classes compiled unmodified (g++ -O2), pixel loop only, shading driver of main.cpp restated"}
+    return base, st["visits"], rays
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--trace-mode", choices=["exact", "fast"], default="exact")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo = rehearsal with ranks sharing a GPU)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-row-step", type=int, default=16)
+    args = ap.parse_args()
+
+    import torch
+    from raytracer_amd import _capi, multigpu
+    from raytracer_amd.device import DeviceScene
+    from raytracer_amd.scene import FlatScene
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("no GPU visible: the trace path has no CPU fallback")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+
+    width = args.width or (3840 if world == 1 else 7680)
+    height = args.height or (2160 if world == 1 else 4320)
+    trace_mode = _capi.TRACE_FAST if args.trace_mode == "fast" else _capi.TRACE_EXACT
+    flat = FlatScene.load(DRAGON).with_size(width, height)
+    scene = DeviceScene(flat, dev_index)
+    params = multigpu.rank_params(width, height, rank, world, trace_mode=trace_mode)
+    nbytes = multigpu.per_rank_bytes(width, height, world) if world > 1 else width * height * 3
+    local = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    image = torch.empty(width * height * 3, dtype=torch.uint8, device="cuda") if (world > 1 and rank == 0) else None
+    gloo = world > 1 and args.backend == "gloo"
+
+    def step():
+        scene.render_device(params, local.data_ptr(), nbytes, stream)
+        if world > 1:
+            src = local.cpu() if gloo else local
+            got = multigpu.gather_to_root(src, world, rank, dist)
+            if rank == 0:
+                got = got.cuda() if gloo else got
+                scene.assemble_tiles(params, world, got.data_ptr(), nbytes, image.data_ptr(), stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    st = scene.stats(stream)
+    rays_local = np.array([st["primary_rays"], st["shadow_rays"], st["reflection_rays"]], dtype=np.int64)
+
+    # per-kernel device time of one more frame (HIP events on the launch stream), outside the timed region
+    scene.set_profiling(True)
+    per_kernel = {}
+    reps = 5
+    for _ in range(reps):
+        scene.render_device(params, local.data_ptr(), nbytes, stream)
+        for name, ms in scene.launch_times(stream):
+            per_kernel.setdefault(name, []).append(ms)
+    scene.set_profiling(False)
+    kern = {k: {"launches_per_frame": len(v) // reps, "ms_per_frame": sum(v) / reps, "avg_launch_ms": sum(v) / len(v)} for k, v in per_kernel.items()}
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        r = torch.tensor(rays_local, device="cpu" if gloo else "cuda")
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rays = r.cpu().numpy()
+    else:
+        rays = rays_local
+
+    if rank == 0:
+        total_rays = int(rays.sum())
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_rays * args.steps / elapsed / 1e6
+        out = {
+            "metric": "Mrays/s (primary+shadow+reflection), Dragon %dx%d maxdepth 5" % (width, height),
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "final_scenes/scene7 (Stanford Dragon, 100000 triangles, 1 point light) %dx%d maxdepth 5 diffuse+specular+shadows+reflections" % (width, height),
+                "trace_mode": args.trace_mode,
+                "parallelism": "single GPU, whole image" if world == 1 else "interleaved %dx%d tiles over %d GPUs, scene replicated, %s gather of packed tiles to rank 0" % (multigpu.TILE_W, multigpu.TILE_H, world, "RCCL" if not gloo else "gloo (rehearsal)"),
+                "scene_source": "flattened by the reference's own parser and Partition build (tests/golden/scene7.flat.npz)",
+            },
+            "rays_per_frame": {"primary": int(rays[0]), "shadow": int(rays[1]), "reflection": int(rays[2])},
+            "kernels": kern,
+        }
+        frame_ms = sum(k["ms_per_frame"] for k in kern.values())
+        out["device_ms_per_frame"] = frame_ms
+        if world == 1 and not args.no_cpu_baseline:
+            base, vis, srays = cpu_baseline_and_visits(flat, width, height, args.cpu_row_step)
+            out["cpu_baseline"] = base
+            # algorithmic bytes per ray kind from the exhaustive walk's visit counts on the sample
+            per_ray = []
+            for k in range(3):
+                n = max(int(srays[k]), 1)
+                per_ray.append((float(vis[k][0]) * NODE_BYTES + float(vis[k][2]) * TRI_BYTES) / n + RAY_STATE_BYTES)
+            frame_bytes = float(rays[0]) * per_ray[0] + float(rays[1]) * per_ray[1] + float(rays[2]) * per_ray[2] + width * height * 3
+            # dominant kernels: everything that walks the tree (primary + trace + shade); resolve is the remainder
+            walk_ms = sum(kern[k]["ms_per_frame"] for k in ("primary", "trace", "shade") if k in kern)
+            achieved = frame_bytes / (walk_ms * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "tree-walking kernels of one frame (k_primary + k_trace + k_shade), %d launches" % sum(kern[k]["launches_per_frame"] for k in ("primary", "trace", "shade") if k in kern),
+                "algorithmic_bytes_per_ray": {"primary": per_ray[0], "shadow": per_ray[1], "reflection": per_ray[2]},
+                "algorithmic_bytes_per_frame": frame_bytes,
+                "note": "bytes = reference-semantics exhaustive walk (box tests x32 B + triangle tests x40 B + 32 B ray state); the device walk is ordered and culled, so it touches far fewer",
+            }
+        print(json.dumps(out), flush=True)
+    scene.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

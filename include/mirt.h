@@ -179,6 +179,18 @@ size_t mirt_tile_buffer_bytes(const mirt_render_params* params);
 /* Counters of the most recent mirt_render_device call on this scene (synchronises hip_stream). */
 int mirt_get_stats(mirt_scene* scene, void* hip_stream, mirt_stats* stats);
 
+/* Per-kernel timing of the frames rendered on this scene.  After mirt_set_profiling(scene, 1) every kernel launch of a
+ * frame is bracketed by HIP events recorded on the frame's own stream; mirt_get_launch_times synchronises that stream and
+ * returns the duration of each launch of the most recent frame in issue order: primary, shade(0), trace(1), shade(1), ...,
+ * resolve.  kinds_out[i] is MIRT_K_PRIMARY / _TRACE / _SHADE / _RESOLVE.  Replaces the reference's wall-clock report
+ * (main.cpp:131,171, 1-second resolution). */
+#define MIRT_K_PRIMARY 0
+#define MIRT_K_TRACE 1
+#define MIRT_K_SHADE 2
+#define MIRT_K_RESOLVE 3
+int mirt_set_profiling(mirt_scene* scene, int enabled);
+int mirt_get_launch_times(mirt_scene* scene, void* hip_stream, float* ms_out, int32_t* kinds_out, uint32_t capacity, uint32_t* n_out);
+
 /* Reassemble an image from `n_ranks` packed tile buffers laid back to back in d_tiles (rank r's buffer at
  * r * per_rank_bytes, rendered with first_tile = r, tile_stride = n_ranks) into d_bgr (width*height*3).
  * The step after the RCCL gather; has no counterpart in the single-threaded reference. */

@@ -120,14 +120,19 @@ class RefOracle:
         self.L.ref_box_intersect(lo.ctypes.data, hi.ctypes.data, o.shape[0], o.ctypes.data, d.ctypes.data, hit.ctypes.data)
         return hit
 
-    def render(self, w=None, h=None, features=_capi.F_ALL, debug=_capi.DEBUG_NONE, row0=0, row1=None, col_step=1):
+    def render(self, w=None, h=None, features=_capi.F_ALL, debug=_capi.DEBUG_NONE, row0=0, row1=None, row_step=1, col_step=1):
         w = w or self.width
         h = h or self.height
         row1 = h if row1 is None else row1
         bgr = np.zeros((h, w, 3), np.uint8)
-        rays = np.zeros(3, np.uint64)
-        secs = self.L.ref_render_rows(self.h, features, debug, w, h, row0, row1, col_step, bgr.ctypes.data, rays.ctypes.data)
-        return bgr, dict(primary=int(rays[0]), shadow=int(rays[1]), reflection=int(rays[2]), seconds=secs)
+        tot = np.zeros(3, np.uint64)
+        secs = 0.0
+        spans = [(row0, row1)] if row_step == 1 else [(r, r + 1) for r in range(row0, row1, row_step)]
+        for a, b in spans:
+            rays = np.zeros(3, np.uint64)
+            secs += self.L.ref_render_rows(self.h, features, debug, w, h, a, b, col_step, bgr.ctypes.data, rays.ctypes.data)
+            tot += rays
+        return bgr, dict(primary=int(tot[0]), shadow=int(tot[1]), reflection=int(tot[2]), seconds=secs)
 
 
 class CPort:
@@ -141,7 +146,7 @@ class CPort:
         L.mirt_oracle_trace_rays.argtypes = [D, C.c_uint64] + [C.c_void_p] * 6
         L.mirt_oracle_primary_rays.argtypes = [D, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.mirt_oracle_render.argtypes = [D, P, C.c_void_p, S, C.c_void_p]
-        L.mirt_oracle_render_rows.argtypes = [D, P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, S]
+        L.mirt_oracle_render_rows.argtypes = [D, P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, S, C.c_void_p]
         L.mirt_oracle_triangle.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 4
         L.mirt_oracle_sphere.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 4
         L.mirt_oracle_box.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64] + [C.c_void_p] * 3
@@ -181,13 +186,18 @@ class CPort:
             out["visits"] = vis
         return bgr, out
 
-    def render_rows(self, w, h, row0, row1, col_step=1, features=_capi.F_ALL):
+    def render_rows(self, w, h, row0, row1, row_step=1, col_step=1, features=_capi.F_ALL):
+        """Bounded sample of the image: every row_step-th row, every col_step-th column.  Returns the image (only the
+        sampled pixels written), ray counts and the [ray kind][box tests, leaf visits, primitive tests] matrix."""
         p = _capi.make_params(w, h, features)
         bgr = np.zeros((h, w, 3), np.uint8)
         st = _capi.Stats()
-        rc = self.L.mirt_oracle_render_rows(C.byref(self.d), C.byref(p), row0, row1, col_step, bgr.ctypes.data, C.byref(st))
+        vis = np.zeros((3, 3), np.uint64)
+        rc = self.L.mirt_oracle_render_rows(C.byref(self.d), C.byref(p), row0, row1, row_step, col_step, bgr.ctypes.data, C.byref(st), vis.ctypes.data)
         assert rc == 0, rc
-        return bgr, st.as_dict()
+        out = st.as_dict()
+        out["visits"] = vis
+        return bgr, out
 
     def triangle(self, v9, origins, dirs):
         v = _f32(v9).reshape(9)

@@ -352,8 +352,8 @@ static int tile_selected(const mirt_render_params* p, uint32_t i, uint32_t j) {
 	return (k % p->tile_stride) == p->first_tile;
 }
 
-static int render_impl(const mirt_scene_desc* d, const mirt_render_params* p, uint32_t row0, uint32_t row1, uint32_t col_step,
-                       uint8_t* bgr, mirt_stats* stats, uint64_t* visits9) {
+static int render_impl(const mirt_scene_desc* d, const mirt_render_params* p, uint32_t row0, uint32_t row1, uint32_t row_step,
+                       uint32_t col_step, uint8_t* bgr, mirt_stats* stats, uint64_t* visits9) {
 	if (!d || !p || !bgr) return MIRT_E_INVALID;
 	rctx rc;
 	memset(&rc, 0, sizeof rc);
@@ -364,7 +364,8 @@ static int render_impl(const mirt_scene_desc* d, const mirt_render_params* p, ui
 	rc.debug = p->debug_mode;
 	rc.count_visits = visits9 != NULL;
 	if (col_step < 1) col_step = 1;
-	for (uint32_t i = row0; i < row1; ++i) {                                      /* main.cpp:137 */
+	if (row_step < 1) row_step = 1;
+	for (uint32_t i = row0; i < row1; i += row_step) {                            /* main.cpp:137 */
 		for (uint32_t j = 0; j < p->width; j += col_step) {                       /* :138 */
 			if (!tile_selected(p, i, j)) continue;
 			ray_t r = cam_ray(&rc.cam, j + 0.5f, i + 0.5f, (int)p->width, (int)p->height); /* :150-152 */
@@ -390,13 +391,13 @@ static int render_impl(const mirt_scene_desc* d, const mirt_render_params* p, ui
 
 int mirt_oracle_render(const mirt_scene_desc* d, const mirt_render_params* p, uint8_t* bgr, mirt_stats* stats, uint64_t* visits9) {
 	if (!p) return MIRT_E_INVALID;
-	return render_impl(d, p, 0, p->height, 1, bgr, stats, visits9);
+	return render_impl(d, p, 0, p->height, 1, 1, bgr, stats, visits9);
 }
 
-int mirt_oracle_render_rows(const mirt_scene_desc* d, const mirt_render_params* p, uint32_t row0, uint32_t row1, uint32_t col_step,
-                            uint8_t* bgr, mirt_stats* stats) {
+int mirt_oracle_render_rows(const mirt_scene_desc* d, const mirt_render_params* p, uint32_t row0, uint32_t row1, uint32_t row_step,
+                            uint32_t col_step, uint8_t* bgr, mirt_stats* stats, uint64_t* visits9) {
 	if (!p || row1 > p->height || row0 > row1) return MIRT_E_INVALID;
-	return render_impl(d, p, row0, row1, col_step, bgr, stats, NULL);
+	return render_impl(d, p, row0, row1, row_step, col_step, bgr, stats, visits9);
 }
 
 int mirt_oracle_trace_rays(const mirt_scene_desc* d, uint64_t n, const float* origins, const float* dirs,

@@ -15,9 +15,9 @@ int mirt_oracle_primary_rays(const mirt_scene_desc* d, uint32_t w, uint32_t h, f
 /* Full image (tile selection in params is honoured: unselected pixels are left untouched).
  * visits9 (may be NULL): box tests, leaf visits, primitive tests for primary / shadow / reflection rays. */
 int mirt_oracle_render(const mirt_scene_desc* d, const mirt_render_params* p, uint8_t* bgr, mirt_stats* stats, uint64_t* visits9);
-/* rows [row0,row1), every col_step-th column: the bounded sample used for CPU timing */
-int mirt_oracle_render_rows(const mirt_scene_desc* d, const mirt_render_params* p, uint32_t row0, uint32_t row1, uint32_t col_step,
-                            uint8_t* bgr, mirt_stats* stats);
+/* every row_step-th row of [row0,row1), every col_step-th column: the bounded sample used for CPU timing */
+int mirt_oracle_render_rows(const mirt_scene_desc* d, const mirt_render_params* p, uint32_t row0, uint32_t row1, uint32_t row_step,
+                            uint32_t col_step, uint8_t* bgr, mirt_stats* stats, uint64_t* visits9);
 /* single primitive / single box, for known-answer tests */
 int mirt_oracle_triangle(const float* v9, uint64_t n, const float* origins, const float* dirs, float* dist, float* normal);
 int mirt_oracle_sphere(const mirt_sphere* s, uint64_t n, const float* origins, const float* dirs, float* dist, float* normal);

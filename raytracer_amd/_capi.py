@@ -16,6 +16,8 @@ F_DIFFUSE, F_SPECULAR, F_SHADOWS, F_REFLECTIONS, F_ALL = 1, 2, 4, 8, 15
 (DEBUG_DIFFUSE_INTENSITY, DEBUG_SPECULAR_INTENSITY, DEBUG_NORMAL_MAP, DEBUG_SHADOW_MAP,
  DEBUG_PRIMARY_MAP, DEBUG_LIGHT_DIRECTION_MAP, DEBUG_NONE) = range(7)
 TRACE_EXACT, TRACE_FAST = 0, 1
+K_PRIMARY, K_TRACE, K_SHADE, K_RESOLVE = range(4)
+KERNEL_NAMES = ["primary", "trace", "shade", "resolve"]
 
 
 class Node(C.Structure):
@@ -88,6 +90,8 @@ SYMBOLS = [
     ("mirt_render_device", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_size_t, C.c_void_p]),
     ("mirt_tile_buffer_bytes", C.c_size_t, [C.POINTER(RenderParams)]),
     ("mirt_get_stats", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
+    ("mirt_set_profiling", C.c_int, [C.c_void_p, C.c_int]),
+    ("mirt_get_launch_times", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     ("mirt_assemble_tiles", C.c_int, [C.c_int, C.POINTER(RenderParams), C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     ("mirt_trace_rays", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mirt_trace_primary_ids", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),

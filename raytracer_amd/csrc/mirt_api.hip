@@ -84,6 +84,11 @@ struct mirt_scene {
 	uint64_t lastPrimary = 0;
 	uint32_t lastFeatures = 0;
 	bool lastValid = false;
+	// optional per-launch timing
+	bool profiling = false;
+	std::vector<hipEvent_t> launchEv;
+	std::vector<int32_t> launchKind;
+	uint32_t nLaunches = 0;
 };
 
 namespace {
@@ -229,18 +234,42 @@ TileGeom tile_geom(const mirt_render_params* p, uint32_t tileW, uint32_t tileH) 
 
 bool packed_layout(const mirt_render_params* p) { return !(p->tile_stride == 1 && p->tile_w == 0 && p->tile_h == 0); }
 
+// event after launch i (event 0 precedes the first launch); only when profiling is on
+void mark(mirt_scene* s, hipStream_t st, int kind) {
+	if (!s->profiling) return;
+	const size_t need = (size_t)s->nLaunches + 2;
+	while (s->launchEv.size() < need) {
+		hipEvent_t e = nullptr;
+		if (hipEventCreate(&e) != hipSuccess) { s->profiling = false; return; }
+		s->launchEv.push_back(e);
+	}
+	if (kind < 0) { (void)hipEventRecord(s->launchEv[0], st); return; }
+	s->launchKind.resize(s->nLaunches + 1);
+	s->launchKind[s->nLaunches] = kind;
+	(void)hipEventRecord(s->launchEv[s->nLaunches + 1], st);
+	s->nLaunches++;
+}
+
 template <int MODE>
 void launch_frame(mirt_scene* s, const DFrame& F, uint8_t* out, hipStream_t st) {
 	const int grid = s->numCUs * 8;
 	int launch = 0;
+	s->nLaunches = 0;
+	mark(s, st, -1);
 	hipLaunchKernelGGL(k_primary<MODE>, dim3(grid), dim3(BLOCK), 0, st, s->ds, F, out, launch++);
+	mark(s, st, MIRT_K_PRIMARY);
 	if (F.debug != D_PRIMARY_MAP) {
 		const int last = (F.features & F_REFLECTIONS) ? s->maxDepth : 0;
 		for (int depth = 0; depth <= last; ++depth) {
-			if (depth > 0) hipLaunchKernelGGL(k_trace<MODE>, dim3(grid), dim3(BLOCK), 0, st, s->ds, F, depth, launch++);
+			if (depth > 0) {
+				hipLaunchKernelGGL(k_trace<MODE>, dim3(grid), dim3(BLOCK), 0, st, s->ds, F, depth, launch++);
+				mark(s, st, MIRT_K_TRACE);
+			}
 			hipLaunchKernelGGL(k_shade<MODE>, dim3(grid), dim3(BLOCK), 0, st, s->ds, F, depth, launch++);
+			mark(s, st, MIRT_K_SHADE);
 		}
 		hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(BLOCK), 0, st, F, out);
+		mark(s, st, MIRT_K_RESOLVE);
 	}
 }
 
@@ -481,6 +510,7 @@ void mirt_scene_destroy(mirt_scene* s) {
 	s->ws.release();
 	if (s->ev0) (void)hipEventDestroy(s->ev0);
 	if (s->ev1) (void)hipEventDestroy(s->ev1);
+	for (hipEvent_t e : s->launchEv) (void)hipEventDestroy(e);
 	if (s->stream) (void)hipStreamDestroy(s->stream);
 	delete s;
 }
@@ -498,6 +528,27 @@ size_t mirt_tile_buffer_bytes(const mirt_render_params* p) {
 int mirt_render_device(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t d_out_bytes, void* hip_stream) {
 	if (!p) return fail(MIRT_E_INVALID, "render params are NULL");
 	return render_async(s, p, d_out, d_out_bytes, (hipStream_t)hip_stream, packed_layout(p));
+}
+
+int mirt_set_profiling(mirt_scene* s, int enabled) {
+	if (!s) return fail(MIRT_E_INVALID, "scene handle is NULL");
+	s->profiling = enabled != 0;
+	s->nLaunches = 0;
+	return MIRT_OK;
+}
+
+int mirt_get_launch_times(mirt_scene* s, void* hip_stream, float* ms_out, int32_t* kinds_out, uint32_t capacity, uint32_t* n_out) {
+	if (!s || !ms_out || !kinds_out || !n_out) return fail(MIRT_E_INVALID, "NULL argument");
+	HIPCHK(hipSetDevice(s->device));
+	HIPCHK(hipStreamSynchronize((hipStream_t)hip_stream));
+	*n_out = 0;
+	if (!s->profiling) return fail(MIRT_E_INVALID, "profiling is off (mirt_set_profiling)");
+	for (uint32_t i = 0; i < s->nLaunches && i < capacity; ++i) {
+		HIPCHK(hipEventElapsedTime(&ms_out[i], s->launchEv[i], s->launchEv[i + 1]));
+		kinds_out[i] = s->launchKind[i];
+		*n_out = i + 1;
+	}
+	return MIRT_OK;
 }
 
 int mirt_get_stats(mirt_scene* s, void* hip_stream, mirt_stats* stats) {

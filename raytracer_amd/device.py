@@ -73,6 +73,17 @@ class DeviceScene:
         _check(self.lib, self.lib.mirt_get_stats(self.h, C.c_void_p(stream_ptr), C.byref(st)))
         return st.as_dict()
 
+    def set_profiling(self, on=True):
+        _check(self.lib, self.lib.mirt_set_profiling(self.h, 1 if on else 0))
+
+    def launch_times(self, stream_ptr=0):
+        """[(kernel name, ms)] of the most recent frame, in issue order (needs set_profiling(True))."""
+        ms = (C.c_float * 96)()
+        kinds = (C.c_int32 * 96)()
+        n = C.c_uint32()
+        _check(self.lib, self.lib.mirt_get_launch_times(self.h, C.c_void_p(stream_ptr), ms, kinds, 96, C.byref(n)))
+        return [(_capi.KERNEL_NAMES[kinds[i]], float(ms[i])) for i in range(n.value)]
+
     def assemble_tiles(self, params, n_ranks, d_tiles_ptr, per_rank_bytes, d_bgr_ptr, stream_ptr=0):
         _check(self.lib, self.lib.mirt_assemble_tiles(self.device, C.byref(params), n_ranks, C.c_void_p(d_tiles_ptr), per_rank_bytes,
                                                      C.c_void_p(d_bgr_ptr), C.c_void_p(stream_ptr)))
