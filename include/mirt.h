@@ -124,13 +124,16 @@ typedef struct mirt_scene_desc {
 #define MIRT_DEBUG_LIGHT_DIRECTION_MAP 5u
 #define MIRT_DEBUG_NONE 6u
 
-/* Arithmetic mode of the traversal and primitive tests.
- *   EXACT: every operation of AABB.cpp:53-72, Triangle.cpp:148-167 and Sphere.cpp:60-82 is evaluated in the
- *          reference's order with IEEE division and square root and no fused multiply-add.
- *   FAST:  reciprocal-multiply slab test and Moller-Trumbore triangle test with the reference's 1e-4
- *          thresholds; hit distances differ from the reference in the last bits. */
+/* How the nearest hit is found.  All three evaluate Triangle.cpp:148-167 and Sphere.cpp:60-82 in the reference's
+ * operation order with IEEE division and square root and no fused multiply-add.
+ *   EXACT:   primitives are enumerated through the library's own hierarchy over the primitives; a candidate counts only
+ *            if one of the Partition leaves that hold it passes AABB::intersect (AABB.cpp:53-72, evaluated exactly).
+ *            Same result as Partition::intersect (Partition.cpp:35-53) including its tie-breaks.
+ *   FAST:    as EXACT without the leaf-box check: differs only for a hit the reference's tree would not have reached.
+ *   REFWALK: walks the Partition tree that was handed over, box by box (cross-check and fallback; slow). */
 #define MIRT_TRACE_EXACT 0u
 #define MIRT_TRACE_FAST 1u
+#define MIRT_TRACE_REFWALK 2u
 
 /* One image, or one rank's share of it.  The image is cut into tile_w x tile_h tiles numbered row-major;
  * tile k is rendered iff k % tile_stride == first_tile.  tile_stride == 1 renders the whole image. */

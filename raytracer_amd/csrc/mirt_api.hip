@@ -2,6 +2,7 @@
 // Host code here only re-packs data and launches kernels; all tracing arithmetic lives in mirt_kernels.hip.
 #include "../../include/mirt.h"
 #include "mirt_kernels.hip"
+#include "mirt_bvh.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -13,6 +14,8 @@
 #include <vector>
 
 #pragma clang fp contract(off)
+
+#define GRID_BLOCKS_PER_CU 8
 
 namespace {
 
@@ -73,7 +76,9 @@ struct mirt_scene {
 	int device = 0;
 	int numCUs = 256;
 	DScene ds;
-	DevBuf nodes, leafs, tris, spheres, materials, lights;
+	DevBuf nodes, leafs, bvh, memb, tris, triInfo, spheres, sphInfo, materials, lights, ovf;
+	bool nested = true;      // reference boxes nested: the primitive hierarchy may be used
+	uint32_t bvhDepth = 0;
 	Workspace ws;
 	hipStream_t stream = nullptr; // used by the synchronous entry points
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -200,7 +205,7 @@ int check_params(const mirt_scene* s, const mirt_render_params* p, uint32_t& til
 	if (p->struct_size != sizeof(mirt_render_params)) return fail(MIRT_E_INVALID, "mirt_render_params.struct_size %u != %zu", p->struct_size, sizeof(mirt_render_params));
 	if (p->width == 0 || p->height == 0 || p->width > 65536 || p->height > 65536) return fail(MIRT_E_INVALID, "image size %ux%u not supported", p->width, p->height);
 	if (p->debug_mode > MIRT_DEBUG_NONE) return fail(MIRT_E_INVALID, "debug_mode %u unknown", p->debug_mode);
-	if (p->trace_mode > MIRT_TRACE_FAST) return fail(MIRT_E_INVALID, "trace_mode %u unknown", p->trace_mode);
+	if (p->trace_mode > MIRT_TRACE_REFWALK) return fail(MIRT_E_INVALID, "trace_mode %u unknown", p->trace_mode);
 	tileW = p->tile_w ? p->tile_w : 32;
 	tileH = p->tile_h ? p->tile_h : 32;
 	if ((tileW & 7) || (tileH & 7) || tileW > 1024 || tileH > 1024) return fail(MIRT_E_INVALID, "tile size %ux%u must be multiples of 8, at most 1024", tileW, tileH);
@@ -234,6 +239,9 @@ TileGeom tile_geom(const mirt_render_params* p, uint32_t tileW, uint32_t tileH) 
 
 bool packed_layout(const mirt_render_params* p) { return !(p->tile_stride == 1 && p->tile_w == 0 && p->tile_h == 0); }
 
+// a tree whose boxes are not nested is walked as it is, whatever mode was asked for
+int effective_mode(const mirt_scene* s, uint32_t mode) { return s->nested ? (int)mode : MODE_REFWALK; }
+
 // event after launch i (event 0 precedes the first launch); only when profiling is on
 void mark(mirt_scene* s, hipStream_t st, int kind) {
 	if (!s->profiling) return;
@@ -252,7 +260,7 @@ void mark(mirt_scene* s, hipStream_t st, int kind) {
 
 template <int MODE>
 void launch_frame(mirt_scene* s, const DFrame& F, uint8_t* out, hipStream_t st) {
-	const int grid = s->numCUs * 8;
+	const int grid = s->numCUs * GRID_BLOCKS_PER_CU;
 	int launch = 0;
 	s->nLaunches = 0;
 	mark(s, st, -1);
@@ -318,8 +326,11 @@ int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 	F.packedTiles = packed ? 1u : 0u;
 	HIPCHK(hipEventRecord(s->ev0, st));
 	HIPCHK(hipMemsetAsync(w.counters.p, 0, CTR_COUNT * 4, st));
-	if (p->trace_mode == MIRT_TRACE_FAST) launch_frame<MODE_FAST>(s, F, (uint8_t*)d_out, st);
-	else launch_frame<MODE_EXACT>(s, F, (uint8_t*)d_out, st);
+	switch (effective_mode(s, p->trace_mode)) {
+	case MODE_FAST: launch_frame<MODE_FAST>(s, F, (uint8_t*)d_out, st); break;
+	case MODE_REFWALK: launch_frame<MODE_REFWALK>(s, F, (uint8_t*)d_out, st); break;
+	default: launch_frame<MODE_EXACT>(s, F, (uint8_t*)d_out, st); break;
+	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(s->ev1, st));
 	s->lastPrimary = g.livePixels;
@@ -363,14 +374,147 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	hipDeviceProp_t prop;
 	HIPCHK(hipGetDeviceProperties(&prop, device));
 
+	// primitive id -> triangle index, or -1 - sphere index; objects that are neither never hit (Shape.cpp:44-46)
+	std::vector<int64_t> primSlot(d->n_prims, INT64_MIN);
+	for (uint32_t i = 0; i < d->n_triangles; ++i) primSlot[d->tri_prim[i]] = (int64_t)i;
+	for (uint32_t i = 0; i < d->n_spheres; ++i) primSlot[d->sphere_prim[i]] = -1 - (int64_t)i;
+
+	// ---- membership lists: per primitive, the reference leaves holding it, in visiting order ------------------------
+	std::vector<uint32_t> mCnt(d->n_prims, 0), mOfs(d->n_prims + 1, 0);
+	for (uint32_t i = 0; i < d->n_nodes; ++i) {
+		const mirt_node& n = d->nodes[i];
+		if (!(n.b & MIRT_LEAF_FLAG)) continue;
+		const uint32_t cnt = n.b & ~MIRT_LEAF_FLAG;
+		for (uint32_t k = 0; k < cnt; ++k) mCnt[d->leaf_prims[n.a + k]]++;
+	}
+	for (uint32_t p = 0; p < d->n_prims; ++p) mOfs[p + 1] = mOfs[p] + mCnt[p];
+	std::vector<float> memb((size_t)mOfs[d->n_prims] * 8, 0.0f);
+	{
+		std::vector<uint32_t> fill(mOfs.begin(), mOfs.end() - 1);
+		for (uint32_t i = 0; i < d->n_nodes; ++i) {
+			const mirt_node& n = d->nodes[i];
+			if (!(n.b & MIRT_LEAF_FLAG)) continue;
+			const uint32_t cnt = n.b & ~MIRT_LEAF_FLAG;
+			for (uint32_t k = 0; k < cnt; ++k) {
+				const uint32_t pos = n.a + k; // rank in the reference's visiting order
+				float* m = memb.data() + (size_t)fill[d->leaf_prims[pos]]++ * 8;
+				m[0] = n.bmin[0]; m[1] = n.bmin[1]; m[2] = n.bmin[2]; memcpy(m + 3, &pos, 4);
+				m[4] = n.bmax[0]; m[5] = n.bmax[1]; m[6] = n.bmax[2]; m[7] = 0.0f;
+			}
+		}
+	}
+	// the hierarchy-plus-membership formulation needs child boxes nested in parent boxes (see mirt_bvh.h)
+	bool nested = true;
+	for (uint32_t i = 0; i < d->n_nodes && nested; ++i) {
+		const mirt_node& n = d->nodes[i];
+		if (n.b & MIRT_LEAF_FLAG) continue;
+		if (n.a != MIRT_NO_CHILD && !Packer::inside(d->nodes[n.a], n)) nested = false;
+		if (n.b != MIRT_NO_CHILD && !Packer::inside(d->nodes[n.b], n)) nested = false;
+	}
+
+	// ---- primitive hierarchy ---------------------------------------------------------------------------------------------
+	// Bounds are padded so that every point the reference's tests can accept lies inside them: a triangle hit P = o + t*d
+	// sits within ~1e-7 * (|v1| + |o|) of the triangle's plane (rounding of t), a sphere hit within
+	// ~1e-7 * |o - c|^2 / r of the surface (rounding of the quadratic).  D bounds |o|: rays start at the eye or on a surface.
+	BvhBuilder bb;
+	float slo[3] = {d->camera.look_from[0], d->camera.look_from[1], d->camera.look_from[2]}, shi[3] = {slo[0], slo[1], slo[2]};
+	for (uint32_t i = 0; i < d->n_triangles; ++i) {
+		const float* v = d->tri_verts + (size_t)i * 9;
+		for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) { slo[k] = fminf(slo[k], v[3 * c + k]); shi[k] = fmaxf(shi[k], v[3 * c + k]); }
+	}
+	std::vector<float> sphBox((size_t)d->n_spheres * 6);
+	for (uint32_t i = 0; i < d->n_spheres; ++i) {
+		const mirt_sphere& sp = d->spheres[i];
+		const float* M = sp.M;
+		for (int k = 0; k < 3; ++k) {
+			const float c = M[0 * 4 + k] * sp.center[0] + M[1 * 4 + k] * sp.center[1] + M[2 * 4 + k] * sp.center[2] + M[3 * 4 + k];
+			const float h = fabsf(sp.radius) * sqrtf(M[0 * 4 + k] * M[0 * 4 + k] + M[1 * 4 + k] * M[1 * 4 + k] + M[2 * 4 + k] * M[2 * 4 + k]);
+			sphBox[(size_t)i * 6 + k] = c;
+			sphBox[(size_t)i * 6 + 3 + k] = h;
+			slo[k] = fminf(slo[k], c - h);
+			shi[k] = fmaxf(shi[k], c + h);
+		}
+	}
+	const float D = sqrtf((shi[0] - slo[0]) * (shi[0] - slo[0]) + (shi[1] - slo[1]) * (shi[1] - slo[1]) + (shi[2] - slo[2]) * (shi[2] - slo[2]));
+	for (uint32_t i = 0; i < d->n_triangles; ++i) {
+		if (mCnt[d->tri_prim[i]] == 0) continue; // in no leaf (dropped by Partition::insert, Partition.cpp:55-71): never tested
+		const float* v = d->tri_verts + (size_t)i * 9;
+		BvhPrim p;
+		float maxabs = 0.0f;
+		for (int k = 0; k < 3; ++k) {
+			p.lo[k] = fminf(v[k], fminf(v[3 + k], v[6 + k]));
+			p.hi[k] = fmaxf(v[k], fmaxf(v[3 + k], v[6 + k]));
+			maxabs = fmaxf(maxabs, fmaxf(fabsf(p.lo[k]), fabsf(p.hi[k])));
+		}
+		const float pad = 1e-5f * (maxabs + D) + 1e-7f;
+		for (int k = 0; k < 3; ++k) { p.lo[k] -= pad; p.hi[k] += pad; }
+		p.ref = i;
+		p.kind = 0;
+		bb.prims.push_back(p);
+	}
+	for (uint32_t i = 0; i < d->n_spheres; ++i) {
+		if (mCnt[d->sphere_prim[i]] == 0) continue;
+		BvhPrim p;
+		for (int k = 0; k < 3; ++k) {
+			const float c = sphBox[(size_t)i * 6 + k], h = sphBox[(size_t)i * 6 + 3 + k];
+			const float ratio = h > 0.0f ? D / h : 0.0f;
+			const float pad = h * (0.01f + 4e-7f * ratio * ratio) + 1e-5f * (fabsf(c) + D) + 1e-7f;
+			p.lo[k] = c - h - pad;
+			p.hi[k] = c + h + pad;
+		}
+		p.ref = i;
+		p.kind = 1;
+		bb.prims.push_back(p);
+	}
+	bb.run();
+
+	// primitives in hierarchy order (then the unreferenced ones), per kind
+	std::vector<uint32_t> triNew(d->n_triangles, 0xffffffffu), sphNew(d->n_spheres, 0xffffffffu), triOld, sphOld;
+	std::vector<uint32_t> kindIndex(bb.prims.size());
+	for (size_t i = 0; i < bb.prims.size(); ++i) {
+		const BvhPrim& p = bb.prims[i];
+		if (p.kind == 0) { kindIndex[i] = (uint32_t)triOld.size(); triNew[p.ref] = (uint32_t)triOld.size(); triOld.push_back(p.ref); }
+		else { kindIndex[i] = (uint32_t)sphOld.size(); sphNew[p.ref] = (uint32_t)sphOld.size(); sphOld.push_back(p.ref); }
+	}
+	for (uint32_t i = 0; i < d->n_triangles; ++i) if (triNew[i] == 0xffffffffu) { triNew[i] = (uint32_t)triOld.size(); triOld.push_back(i); }
+	for (uint32_t i = 0; i < d->n_spheres; ++i) if (sphNew[i] == 0xffffffffu) { sphNew[i] = (uint32_t)sphOld.size(); sphOld.push_back(i); }
+	if (triOld.size() > BVH_FIRST_MASK || sphOld.size() > BVH_FIRST_MASK) return fail(MIRT_E_INVALID, "more than %u primitives of one kind", BVH_FIRST_MASK);
+
+	// wide nodes of the hierarchy
+	std::vector<float> bvhWide;
+	uint32_t bvhRoot = BVH_DONE;
+	float bvhMin[3] = {0, 0, 0}, bvhMax[3] = {-1, -1, -1};
+	if (!bb.nodes.empty()) {
+		struct Emit {
+			const BvhBuilder& bb;
+			const std::vector<uint32_t>& kindIndex;
+			std::vector<float>& out;
+			uint32_t leafRef(const BvhNode& n) const {
+				return BVH_LEAF | (n.kind ? BVH_SPHERES : 0u) | ((n.count - 1) << BVH_COUNT_SHIFT) | kindIndex[n.first];
+			}
+			uint32_t ref(int32_t i) { return bb.nodes[i].left < 0 ? leafRef(bb.nodes[i]) : emit(i); }
+			uint32_t emit(int32_t i) {
+				const uint32_t me = (uint32_t)(out.size() / 16);
+				out.resize(out.size() + 16, 0.0f);
+				const BvhNode n = bb.nodes[i];
+				const BvhNode &l = bb.nodes[n.left], &r = bb.nodes[n.right];
+				const uint32_t lr = ref(n.left), rr = ref(n.right);
+				float* w = out.data() + (size_t)me * 16;
+				memcpy(w + 0, l.lo, 12); memcpy(w + 3, &lr, 4);
+				memcpy(w + 4, l.hi, 12); memcpy(w + 7, &rr, 4);
+				memcpy(w + 8, r.lo, 12);
+				memcpy(w + 12, r.hi, 12);
+				return me;
+			}
+		} em = {bb, kindIndex, bvhWide};
+		bvhRoot = em.ref(0);
+		memcpy(bvhMin, bb.nodes[0].lo, 12);
+		memcpy(bvhMax, bb.nodes[0].hi, 12);
+	}
+
+	// ---- the reference tree as it is (MODE_REFWALK) ------------------------------------------------------------------------
 	Packer pk;
 	pk.d = d;
-	// primitive id -> typed reference
-	pk.primSlot.assign(d->n_prims, INT64_MIN);
-	for (uint32_t i = 0; i < d->n_triangles; ++i) pk.primSlot[d->tri_prim[i]] = (int64_t)i;
-	for (uint32_t i = 0; i < d->n_spheres; ++i) pk.primSlot[d->sphere_prim[i]] = -1 - (int64_t)i;
-	// leaf stream in node (= depth-first) order; objects that are neither triangle nor sphere never hit
-	// (Shape::intersect, Shape.cpp:44-46) and are dropped
 	pk.leafPos.assign(d->n_nodes, 0);
 	for (uint32_t i = 0; i < d->n_nodes; ++i) {
 		const mirt_node& n = d->nodes[i];
@@ -381,9 +525,9 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		pk.stream.push_back(0);
 		uint32_t kept = 0;
 		for (uint32_t k = 0; k < cnt; ++k) {
-			const int64_t sl = pk.primSlot[d->leaf_prims[n.a + k]];
+			const int64_t sl = primSlot[d->leaf_prims[n.a + k]];
 			if (sl == INT64_MIN) continue;
-			pk.stream.push_back(sl >= 0 ? (uint32_t)sl : (PRIM_SPHERE | (uint32_t)(-1 - sl)));
+			pk.stream.push_back(sl >= 0 ? triNew[(uint32_t)sl] : (PRIM_SPHERE | sphNew[(uint32_t)(-1 - sl)]));
 			++kept;
 		}
 		pk.stream[at] = kept;
@@ -394,10 +538,11 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	if (!s) return fail(MIRT_E_NOMEM, "out of host memory");
 	s->device = device;
 	s->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	s->nested = nested;
 	memset(&s->ds, 0, sizeof s->ds);
 	DScene& ds = s->ds;
 	ds.rootRef = REF_NONE;
-	for (int k = 0; k < 3; ++k) { ds.rootMin[k] = 0.0f; ds.rootMax[k] = -1.0f; } // misses every ray when there is no tree
+	for (int k = 0; k < 3; ++k) { ds.rootMin[k] = 0.0f; ds.rootMax[k] = -1.0f; }
 	if (d->n_nodes) {
 		const uint32_t r = pk.skipChain(0);
 		const mirt_node& rn = d->nodes[r];
@@ -409,34 +554,45 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		}
 	}
 	s->wideDepth = pk.maxDepth;
+	s->bvhDepth = bb.maxDepth;
+	ds.bvhRoot = bvhRoot;
+	memcpy(ds.bvhMin, bvhMin, 12);
+	memcpy(ds.bvhMax, bvhMax, 12);
 
-	// triangles: { N, dot(v1,N) } { v1, area } { v2, prim } { v3, material }
-	std::vector<float> tris((size_t)d->n_triangles * 16);
-	for (uint32_t i = 0; i < d->n_triangles; ++i) {
+	// triangles: { N, dot(v1,N) } { v1, area } { v2, 0 } { v3, 0 } in hierarchy order
+	std::vector<float> tris((size_t)d->n_triangles * 16, 0.0f);
+	std::vector<uint32_t> triInfo((size_t)d->n_triangles * 4, 0);
+	for (uint32_t ni = 0; ni < d->n_triangles; ++ni) {
+		const uint32_t i = triOld[ni];
 		const float* v = d->tri_verts + (size_t)i * 9;
 		const h3 v1 = H3(v[0], v[1], v[2]), v2 = H3(v[3], v[4], v[5]), v3 = H3(v[6], v[7], v[8]);
 		const h3 N = hnorm(hcross(hsub(v2, v1), hsub(v3, v1)));      // Triangle.cpp:173-175
 		const float dv = hdot(v1, N);                                // Triangle.cpp:153
 		const h3 e1 = hsub(v3, v2), e2 = hsub(v1, v3);               // Triangle.cpp:148-149
 		const float area = hdot(hcross(e1, e2), N) / 2.0f;           // Triangle.cpp:162
-		float* t = tris.data() + (size_t)i * 16;
+		float* t = tris.data() + (size_t)ni * 16;
 		t[0] = N.x; t[1] = N.y; t[2] = N.z; t[3] = dv;
 		t[4] = v1.x; t[5] = v1.y; t[6] = v1.z; t[7] = area;
-		t[8] = v2.x; t[9] = v2.y; t[10] = v2.z; memcpy(t + 11, &d->tri_prim[i], 4);
-		t[12] = v3.x; t[13] = v3.y; t[14] = v3.z; memcpy(t + 15, &d->prim_material[d->tri_prim[i]], 4);
+		t[8] = v2.x; t[9] = v2.y; t[10] = v2.z;
+		t[12] = v3.x; t[13] = v3.y; t[14] = v3.z;
+		const uint32_t prim = d->tri_prim[i];
+		uint32_t* inf = triInfo.data() + (size_t)ni * 4;
+		inf[0] = prim; inf[1] = d->prim_material[prim]; inf[2] = mOfs[prim]; inf[3] = mCnt[prim];
 	}
-	// spheres: { c, powf(r,2) } M[4] Minv[4] { prim, material, r, 0 }
-	std::vector<float> sph((size_t)d->n_spheres * 40);
-	for (uint32_t i = 0; i < d->n_spheres; ++i) {
+	// spheres: { c, powf(r,2) } M[4] Minv[4]
+	std::vector<float> sph((size_t)d->n_spheres * SPHERE_F4 * 4, 0.0f);
+	std::vector<uint32_t> sphInfo((size_t)d->n_spheres * 4, 0);
+	for (uint32_t ni = 0; ni < d->n_spheres; ++ni) {
+		const uint32_t i = sphOld[ni];
 		const mirt_sphere& sp = d->spheres[i];
-		float* t = sph.data() + (size_t)i * 40;
+		float* t = sph.data() + (size_t)ni * SPHERE_F4 * 4;
 		t[0] = sp.center[0]; t[1] = sp.center[1]; t[2] = sp.center[2];
 		t[3] = powf(sp.radius, 2.0f);                                // Sphere.cpp:64 glm::pow(float,float)
 		memcpy(t + 4, sp.M, 64);
 		memcpy(t + 20, sp.Minv, 64);
-		memcpy(t + 36, &d->sphere_prim[i], 4);
-		memcpy(t + 37, &d->prim_material[d->sphere_prim[i]], 4);
-		t[38] = sp.radius; t[39] = 0.0f;
+		const uint32_t prim = d->sphere_prim[i];
+		uint32_t* inf = sphInfo.data() + (size_t)ni * 4;
+		inf[0] = prim; inf[1] = d->prim_material[prim]; inf[2] = mOfs[prim]; inf[3] = mCnt[prim];
 	}
 	std::vector<float> mats((size_t)d->n_materials * 16, 0.0f);
 	for (uint32_t i = 0; i < d->n_materials; ++i) {
@@ -480,10 +636,20 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 
 	e = upload(s->nodes, pk.wide.data(), pk.wide.size() * 4);
 	if (!e) e = upload(s->leafs, pk.stream.data(), pk.stream.size() * 4);
+	if (!e) e = upload(s->bvh, bvhWide.data(), bvhWide.size() * 4);
+	if (!e) e = upload(s->memb, memb.data(), memb.size() * 4);
 	if (!e) e = upload(s->tris, tris.data(), tris.size() * 4);
+	if (!e) e = upload(s->triInfo, triInfo.data(), triInfo.size() * 4);
 	if (!e) e = upload(s->spheres, sph.data(), sph.size() * 4);
+	if (!e) e = upload(s->sphInfo, sphInfo.data(), sphInfo.size() * 4);
 	if (!e) e = upload(s->materials, mats.data(), mats.size() * 4);
 	if (!e) e = upload(s->lights, lights.data(), lights.size() * 4);
+	ds.ovf = nullptr;
+	ds.ovfStride = (uint32_t)s->numCUs * GRID_BLOCKS_PER_CU * BLOCK;
+	if (!e && bb.maxDepth + 1 > STACK_LDS) {
+		e = s->ovf.ensure((size_t)(bb.maxDepth + 1 - STACK_LDS) * ds.ovfStride * 4);
+		ds.ovf = (uint32_t*)s->ovf.p;
+	}
 	if (!e && hipStreamCreate(&s->stream) != hipSuccess) e = fail(MIRT_E_DEVICE, "hipStreamCreate failed");
 	if (!e && (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess)) e = fail(MIRT_E_DEVICE, "hipEventCreate failed");
 	if (e) {
@@ -494,8 +660,12 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	}
 	ds.nodes = (const float4*)s->nodes.p;
 	ds.leafs = (const uint32_t*)s->leafs.p;
+	ds.bvh = (const float4*)s->bvh.p;
+	ds.memb = (const float4*)s->memb.p;
 	ds.tris = (const float4*)s->tris.p;
+	ds.triInfo = (const uint4*)s->triInfo.p;
 	ds.spheres = (const float4*)s->spheres.p;
+	ds.sphInfo = (const uint4*)s->sphInfo.p;
 	ds.materials = (const float4*)s->materials.p;
 	ds.lights = (const float4*)s->lights.p;
 	*out = s;
@@ -506,7 +676,8 @@ void mirt_scene_destroy(mirt_scene* s) {
 	if (!s) return;
 	(void)hipSetDevice(s->device);
 	if (s->stream) (void)hipStreamSynchronize(s->stream);
-	s->nodes.release(); s->leafs.release(); s->tris.release(); s->spheres.release(); s->materials.release(); s->lights.release();
+	s->nodes.release(); s->leafs.release(); s->bvh.release(); s->memb.release(); s->tris.release(); s->triInfo.release();
+	s->spheres.release(); s->sphInfo.release(); s->materials.release(); s->lights.release(); s->ovf.release();
 	s->ws.release();
 	if (s->ev0) (void)hipEventDestroy(s->ev0);
 	if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -610,7 +781,7 @@ int mirt_assemble_tiles(int device, const mirt_render_params* p, uint32_t n_rank
 
 int mirt_trace_rays(mirt_scene* s, uint32_t trace_mode, uint64_t n, const float* origins, const float* dirs, int32_t* prim_id_out, float* dist_out, float* normal_out) {
 	if (!s) return fail(MIRT_E_INVALID, "scene handle is NULL");
-	if (trace_mode > MIRT_TRACE_FAST) return fail(MIRT_E_INVALID, "trace_mode %u unknown", trace_mode);
+	if (trace_mode > MIRT_TRACE_REFWALK) return fail(MIRT_E_INVALID, "trace_mode %u unknown", trace_mode);
 	if (n == 0) return MIRT_OK;
 	if (!origins || !dirs || !prim_id_out || !dist_out) return fail(MIRT_E_INVALID, "NULL ray or result array");
 	HIPCHK(hipSetDevice(s->device));
@@ -622,9 +793,12 @@ int mirt_trace_rays(mirt_scene* s, uint32_t trace_mode, uint64_t n, const float*
 	if (!e) e = dist.ensure(n * 4);
 	if (!e && normal_out) e = nrm.ensure(n * 12);
 	if (!e) {
-		const int grid = (int)((n + BLOCK - 1) / BLOCK < (uint64_t)s->numCUs * 8 ? (n + BLOCK - 1) / BLOCK : (uint64_t)s->numCUs * 8);
-		if (trace_mode == MIRT_TRACE_FAST)
+		const int grid = (int)((n + BLOCK - 1) / BLOCK < (uint64_t)s->numCUs * GRID_BLOCKS_PER_CU ? (n + BLOCK - 1) / BLOCK : (uint64_t)s->numCUs * GRID_BLOCKS_PER_CU);
+		const int mode = effective_mode(s, trace_mode);
+		if (mode == MODE_FAST)
 			hipLaunchKernelGGL(k_trace_list<MODE_FAST>, dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, n, (const float*)o.p, (const float*)d.p, (int32_t*)id.p, (float*)dist.p, (float*)nrm.p);
+		else if (mode == MODE_REFWALK)
+			hipLaunchKernelGGL(k_trace_list<MODE_REFWALK>, dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, n, (const float*)o.p, (const float*)d.p, (int32_t*)id.p, (float*)dist.p, (float*)nrm.p);
 		else
 			hipLaunchKernelGGL(k_trace_list<MODE_EXACT>, dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, n, (const float*)o.p, (const float*)d.p, (int32_t*)id.p, (float*)dist.p, (float*)nrm.p);
 		hipError_t he = hipGetLastError();
@@ -640,7 +814,7 @@ int mirt_trace_rays(mirt_scene* s, uint32_t trace_mode, uint64_t n, const float*
 
 int mirt_trace_primary_ids(mirt_scene* s, uint32_t trace_mode, uint32_t width, uint32_t height, int32_t* prim_id_out, float* dist_out) {
 	if (!s) return fail(MIRT_E_INVALID, "scene handle is NULL");
-	if (trace_mode > MIRT_TRACE_FAST) return fail(MIRT_E_INVALID, "trace_mode %u unknown", trace_mode);
+	if (trace_mode > MIRT_TRACE_REFWALK) return fail(MIRT_E_INVALID, "trace_mode %u unknown", trace_mode);
 	if (!prim_id_out || !dist_out || width == 0 || height == 0) return fail(MIRT_E_INVALID, "NULL result array or empty image");
 	HIPCHK(hipSetDevice(s->device));
 	const uint64_t n = (uint64_t)width * height;
@@ -648,9 +822,12 @@ int mirt_trace_primary_ids(mirt_scene* s, uint32_t trace_mode, uint32_t width, u
 	int e = id.ensure(n * 4);
 	if (!e) e = dist.ensure(n * 4);
 	if (!e) {
-		const int grid = (int)((n + BLOCK - 1) / BLOCK < (uint64_t)s->numCUs * 8 ? (n + BLOCK - 1) / BLOCK : (uint64_t)s->numCUs * 8);
-		if (trace_mode == MIRT_TRACE_FAST)
+		const int grid = (int)((n + BLOCK - 1) / BLOCK < (uint64_t)s->numCUs * GRID_BLOCKS_PER_CU ? (n + BLOCK - 1) / BLOCK : (uint64_t)s->numCUs * GRID_BLOCKS_PER_CU);
+		const int mode = effective_mode(s, trace_mode);
+		if (mode == MODE_FAST)
 			hipLaunchKernelGGL(k_primary_ids<MODE_FAST>, dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, width, height, (int32_t*)id.p, (float*)dist.p);
+		else if (mode == MODE_REFWALK)
+			hipLaunchKernelGGL(k_primary_ids<MODE_REFWALK>, dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, width, height, (int32_t*)id.p, (float*)dist.p);
 		else
 			hipLaunchKernelGGL(k_primary_ids<MODE_EXACT>, dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, width, height, (int32_t*)id.p, (float*)dist.p);
 		hipError_t he = hipGetLastError();

@@ -1,0 +1,157 @@
+// Host-side builder of the device acceleration structure: a binned-SAH bounding volume hierarchy over the scene's
+// PRIMITIVES (each primitive exactly once), used as a conservative filter in front of the reference's own tests.
+//
+// Why this is the same function as the reference's tree walk.  Partition::intersect (Partition.cpp:35-53) tests a
+// primitive A exactly when A sits in a leaf whose box, and all ancestor boxes, pass AABB::intersect.  Child boxes are
+// halves of their parent's box (AABB::splitLeft/Right, AABB.cpp:121-155), and AABB::intersect's t-values are monotone in
+// the box bounds (IEEE subtraction and division are monotone), so "leaf box hit" implies "every ancestor hit": A is
+// tested  <=>  some leaf holding A has its own box hit.  The result of the walk is therefore
+//     argmin over { A : A->intersect(ray) valid  and  exists leaf L containing A with L.box hit }  of (dist, first visit)
+// and any structure that enumerates a superset of those A -- here: primitives whose padded bounds the ray crosses --
+// followed by the exact "is A in a hit leaf" check gives the identical answer.  mirt_scene_create verifies the nesting
+// premise on the tree it is handed and falls back to walking that tree as it is when the premise does not hold.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+struct BvhPrim {
+	float lo[3], hi[3];
+	uint32_t ref; // caller's handle
+	uint32_t kind; // 0 triangle, 1 sphere: leaves are homogeneous
+};
+
+struct BvhNode {
+	float lo[3], hi[3];
+	int32_t left, right; // children, or -1/-1 for a leaf
+	uint32_t first, count; // leaf: range in the ordered primitive list
+	uint32_t kind;
+};
+
+struct BvhBuilder {
+	static const int BINS = 16;
+	static const uint32_t LEAF_MAX = 4;
+	static const int SAH_DEPTH = 28; // below this depth splits are balanced medians, which bounds the total depth
+
+	std::vector<BvhPrim> prims; // reordered in place: leaf ranges are contiguous
+	std::vector<BvhNode> nodes;
+	uint32_t maxDepth = 0;
+
+	static float area(const float* lo, const float* hi) {
+		const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+		return 2.0f * (dx * dy + dy * dz + dz * dx);
+	}
+	static void grow(float* lo, float* hi, const float* plo, const float* phi) {
+		for (int k = 0; k < 3; ++k) {
+			lo[k] = plo[k] < lo[k] ? plo[k] : lo[k];
+			hi[k] = phi[k] > hi[k] ? phi[k] : hi[k];
+		}
+	}
+
+	int32_t build(uint32_t start, uint32_t end, uint32_t depth) {
+		const int32_t me = (int32_t)nodes.size();
+		nodes.push_back(BvhNode());
+		if (depth > maxDepth) maxDepth = depth;
+		float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+		float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+		bool mixed = false;
+		for (uint32_t i = start; i < end; ++i) {
+			grow(lo, hi, prims[i].lo, prims[i].hi);
+			float c[3];
+			for (int k = 0; k < 3; ++k) c[k] = 0.5f * (prims[i].lo[k] + prims[i].hi[k]);
+			grow(clo, chi, c, c);
+			mixed |= prims[i].kind != prims[start].kind;
+		}
+		BvhNode n;
+		memcpy(n.lo, lo, 12);
+		memcpy(n.hi, hi, 12);
+		n.left = n.right = -1;
+		n.first = start;
+		n.count = end - start;
+		n.kind = prims[start].kind;
+		const uint32_t cnt = end - start;
+		if (cnt <= LEAF_MAX && !mixed) { nodes[me] = n; return me; }
+
+		uint32_t mid = start;
+		if (mixed && cnt <= LEAF_MAX) {
+			// small mixed range: split by kind so that every leaf holds one kind of primitive
+			mid = (uint32_t)(std::partition(prims.begin() + start, prims.begin() + end, [](const BvhPrim& p) { return p.kind == 0; }) - prims.begin());
+		}
+		else {
+			int axis = 0;
+			float ext = chi[0] - clo[0];
+			for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > ext) { ext = chi[k] - clo[k]; axis = k; }
+			bool done = false;
+			if (ext > 0.0f && depth < (uint32_t)SAH_DEPTH) {
+				// binned SAH on the axis of largest centroid extent
+				uint32_t bc[BINS] = {0};
+				float blo[BINS][3], bhi[BINS][3];
+				for (int b = 0; b < BINS; ++b) for (int k = 0; k < 3; ++k) { blo[b][k] = INFINITY; bhi[b][k] = -INFINITY; }
+				const float scale = (float)BINS / ext;
+				for (uint32_t i = start; i < end; ++i) {
+					const float c = 0.5f * (prims[i].lo[axis] + prims[i].hi[axis]);
+					int b = (int)((c - clo[axis]) * scale);
+					b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+					bc[b]++;
+					grow(blo[b], bhi[b], prims[i].lo, prims[i].hi);
+				}
+				float rightArea[BINS];
+				uint32_t rightCnt[BINS];
+				float rlo[3] = {INFINITY, INFINITY, INFINITY}, rhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+				uint32_t rc = 0;
+				for (int b = BINS - 1; b > 0; --b) {
+					if (bc[b]) grow(rlo, rhi, blo[b], bhi[b]);
+					rc += bc[b];
+					rightArea[b] = rc ? area(rlo, rhi) : 0.0f;
+					rightCnt[b] = rc;
+				}
+				float llo[3] = {INFINITY, INFINITY, INFINITY}, lhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+				uint32_t lc = 0;
+				float bestCost = INFINITY;
+				int bestBin = -1;
+				for (int b = 0; b < BINS - 1; ++b) {
+					if (bc[b]) grow(llo, lhi, blo[b], bhi[b]);
+					lc += bc[b];
+					if (lc == 0 || rightCnt[b + 1] == 0) continue;
+					const float cost = area(llo, lhi) * (float)lc + rightArea[b + 1] * (float)rightCnt[b + 1];
+					if (cost < bestCost) { bestCost = cost; bestBin = b; }
+				}
+				if (bestBin >= 0) {
+					const float ca = clo[axis];
+					mid = (uint32_t)(std::partition(prims.begin() + start, prims.begin() + end, [=](const BvhPrim& p) {
+						const float c = 0.5f * (p.lo[axis] + p.hi[axis]);
+						int b = (int)((c - ca) * scale);
+						b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+						return b <= bestBin;
+					}) - prims.begin());
+					done = mid > start && mid < end;
+				}
+			}
+			if (!done) {
+				// balanced median split (also the fallback for coincident centroids)
+				mid = start + cnt / 2;
+				std::nth_element(prims.begin() + start, prims.begin() + mid, prims.begin() + end, [=](const BvhPrim& a, const BvhPrim& b) {
+					return (a.lo[axis] + a.hi[axis]) < (b.lo[axis] + b.hi[axis]);
+				});
+			}
+		}
+		const int32_t l = build(start, mid, depth + 1);
+		const int32_t r = build(mid, end, depth + 1);
+		n.left = l;
+		n.right = r;
+		nodes[me] = n;
+		return me;
+	}
+
+	void run() {
+		nodes.clear();
+		maxDepth = 0;
+		if (!prims.empty()) {
+			nodes.reserve(prims.size());
+			build(0, (uint32_t)prims.size(), 0);
+		}
+	}
+};

@@ -1,30 +1,33 @@
 // Device-side data layout of a mirt_scene (internal; the public ABI is include/mirt.h).
 //
-// The public flattened Partition tree (one box per node) is re-packed at mirt_scene_create into a layout
-// built for one-fetch-per-level traversal on CDNA4:
+// mirt_scene_create re-packs the flattened scene into two structures:
 //
-//   wide node, 64 B = 4 x float4 (one 64-B L2 sector, fetched by a single lane as 4 dwordx4 loads):
-//       q0 = { left.bmin.xyz,  left_ref  }     q1 = { left.bmax.xyz,  right_ref }
-//       q2 = { right.bmin.xyz, 0 }             q3 = { right.bmax.xyz, 0 }
-//     *_ref : REF_NONE | REF_LEAF|position-in-leaf-stream | index of another wide node
-//     The boxes are the reference's own child boxes (PartitionNode::box), so each child's hit/miss decision is
-//     AABB::intersect's decision for that node.  Interior nodes with a single child (Partition.cpp:90-97 deletes
-//     an empty sibling) are skipped when the child box is contained in the parent box: child hit => parent hit
-//     by monotonicity of IEEE subtraction and division, so the set of leaves a ray reaches is unchanged.
+// (1) The primitive hierarchy ("bvh"): a binned-SAH BVH over the primitives, each primitive once, built on the host
+//     (mirt_bvh.h).  It is a conservative FILTER: it only decides which primitives are tested at all.
+//       wide node, 64 B = 4 x float4, fetched by one lane as 4 dwordx4 loads of one 64-B sector pair:
+//           q0 = { left.lo.xyz,  left_ref  }   q1 = { left.hi.xyz,  right_ref }
+//           q2 = { right.lo.xyz, 0 }           q3 = { right.hi.xyz, 0 }
+//       ref: BVH_DONE | interior node index | BVH_LEAF [| BVH_SPHERES] | (count-1) << 27 | first
+//       A leaf names `count` (1..8) consecutive records of the triangle or sphere array: no indirection.
+//     Triangles and spheres are stored in hierarchy order.
 //
-//   leaf stream (uint32): for every leaf, in the reference's depth-first order: count, then `count` primitive
-//     references (bit 31 = sphere, low bits = index into tris / spheres).  The position of an entry in this
-//     stream is its rank in the reference's visiting order; ties in distance are resolved towards the lower
-//     position, which reproduces "first object in a leaf wins" (Partition.h:33) and "left subtree wins"
-//     (Partition.cpp:47) under any traversal order.
+// (2) The membership lists ("memb"): for every primitive, the leaves of the REFERENCE's Partition tree that hold it,
+//     in the reference's depth-first order, each as { leaf.bmin.xyz, position } { leaf.bmax.xyz, 0 } (32 B).
+//     `position` is the index of that (leaf, primitive) entry in mirt_scene_desc::leaf_prims, i.e. its rank in the
+//     reference's visiting order.  A candidate hit counts only if one of these leaf boxes passes AABB::intersect
+//     (evaluated with the reference's exact arithmetic); the first one that does gives the tie-break rank.
+//     This reproduces Partition::intersect's result exactly (argument in mirt_bvh.h).
 //
-//   triangle, 64 B = 4 x float4:  { N.xyz, dot(v1,N) } { v1.xyz, area } { v2.xyz, prim id } { v3.xyz, material }
+// (3) The reference tree itself, as wide nodes with the reference's own boxes plus a count-prefixed leaf stream,
+//     walked exhaustively-equivalent by MODE_REFWALK.  Used as the fallback when the handed-over tree's boxes are
+//     not nested, and by tests to cross-check (1)+(2) at full image sizes.
+//
+//   triangle, 64 B = 4 x float4:  { N.xyz, dot(v1,N) } { v1.xyz, area } { v2.xyz, 0 } { v3.xyz, 0 }
 //     N = normalize(cross(v2-v1, v3-v1)), dot(v1,N) and area = dot(cross(e1,e2),N)/2 are evaluated on the host with
 //     exactly the operations Triangle::intersect performs per call (Triangle.cpp:151-153,162), so loading them
 //     is bit-identical to recomputing them.
-//
-//   sphere, 160 B = 10 x float4: { c.xyz, powf(r,2) } M columns 0..3, inverse(M) columns 0..3, { prim id, material, r, 0 }
-//
+//   sphere, 144 B = 9 x float4: { c.xyz, powf(r,2) } M columns 0..3, inverse(M) columns 0..3
+//   info (per triangle / per sphere), 16 B: { primitive id, material index, memb offset, memb count }
 //   material, 64 B = 4 x float4: { diffuse, shininess } { specular, 0 } { emission, 0 } { ambient, 0 }
 //   light, 32 B = 2 x float4:    { location.xyzw } { color.rgb, 0 }
 #pragma once
@@ -34,7 +37,14 @@
 #define REF_NONE 0xffffffffu
 #define REF_LEAF 0x80000000u
 #define PRIM_SPHERE 0x80000000u
+#define BVH_DONE 0xffffffffu
+#define BVH_LEAF 0x80000000u
+#define BVH_SPHERES 0x40000000u
+#define BVH_COUNT_SHIFT 27
+#define BVH_FIRST_MASK 0x07ffffffu
 #define MIRT_MAX_DEPTH_LIMIT 30
+
+#define SPHERE_F4 9
 
 struct DCamera {
 	float eye[3], u[3], v[3], w[3];
@@ -42,14 +52,27 @@ struct DCamera {
 };
 
 struct DScene {
+	// (1) primitive hierarchy
+	const float4* bvh;
+	const float4* tris;
+	const uint4* triInfo;
+	const float4* spheres;
+	const uint4* sphInfo;
+	// (2) membership lists
+	const float4* memb;
+	// traversal stack overflow area (entries beyond the LDS part), [level][global thread]
+	uint32_t* ovf;
+	uint32_t ovfStride;
+	uint32_t bvhRoot;
+	float bvhMin[3], bvhMax[3];
+	// (3) reference tree
 	const float4* nodes;
 	const uint32_t* leafs;
-	const float4* tris;
-	const float4* spheres;
-	const float4* materials;
-	const float4* lights;
 	float rootMin[3], rootMax[3];
 	uint32_t rootRef;
+	// shading inputs
+	const float4* materials;
+	const float4* lights;
 	uint32_t nLights;
 	int32_t maxDepth;
 	float atten[3];

@@ -34,6 +34,7 @@
 
 #define MODE_EXACT 0
 #define MODE_FAST 1
+#define MODE_REFWALK 2
 
 struct f3 {
 	float x, y, z;
@@ -65,7 +66,7 @@ struct Hit {
 struct RayCtx {
 	f3 o, d;
 	f3 e;      // direction with AABB.cpp:53-58's substitution: |d| < 1e-5 -> +1e-5
-	f3 ie;     // 1/e (MODE_FAST only)
+	f3 ie;     // 1/d for the hierarchy's conservative box filter
 	float invLen; // 1/|d|, used only for conservative culling
 };
 
@@ -76,7 +77,11 @@ __device__ __forceinline__ RayCtx make_ray(f3 o, f3 d) {
 	r.e.x = (fabsf(d.x - 0.0f) < 0.00001f) ? 0.00001f : d.x;
 	r.e.y = (fabsf(d.y - 0.0f) < 0.00001f) ? 0.00001f : d.y;
 	r.e.z = (fabsf(d.z - 0.0f) < 0.00001f) ? 0.00001f : d.z;
-	r.ie = F3(1.0f / r.e.x, 1.0f / r.e.y, 1.0f / r.e.z);
+	// reciprocal of the TRUE direction for the hierarchy's conservative filter (tiny components clamped, sign kept)
+	const float sx = fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x;
+	const float sy = fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y;
+	const float sz = fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z;
+	r.ie = F3(1.0f / sx, 1.0f / sy, 1.0f / sz);
 	r.invLen = inv_sqrt(dot3(d, d));
 	return r;
 }
@@ -203,20 +208,21 @@ __device__ __forceinline__ float sphere_hit(const RayCtx& r, const float4* __res
 	return length3(r.o - F3(pw.x, pw.y, pw.z));       // :82
 }
 
-// Walk of the wide tree.  ANY = false: nearest hit under the reference's tie rules.  ANY = true: is there a hit with
-// dist < limit (the shadow query of main.cpp:223-224, where "closest.dist >= length(lightDir)" decides).
-//
+// ---- MODE_REFWALK: walk of the reference's own tree ---------------------------------------------------------------
+// ANY = false: nearest hit under the reference's tie rules.  ANY = true: is there a hit with dist < limit (the shadow
+// query of main.cpp:223-224, where "closest.dist >= length(lightDir)" decides).
 // Children are visited nearer-first and a subtree is skipped when its entry parameter exceeds `tcull`, a bound kept
 // slightly beyond the best distance so far; every candidate at a distance <= best is still visited, so the result
-// equals the reference's exhaustive walk (Partition.cpp:42-52).
-template <int MODE, bool ANY>
-__device__ __forceinline__ bool traverse(const DScene& S, const RayCtx& r, float limit, Hit& best) {
+// equals the reference's exhaustive walk (Partition.cpp:42-52).  Stack in private memory: this mode is the fallback
+// and the cross-check, not the fast path.
+template <bool ANY>
+__device__ __noinline__ bool traverse_ref(const DScene& S, const RayCtx& r, float limit, Hit& best) {
 	best.dist = __builtin_inff();
 	best.ref = REF_NONE;
 	best.pos = 0xffffffffu;
 	float tcull = ANY ? (limit * r.invLen * 1.0001f + 1e-5f) : __builtin_inff();
 	float tn;
-	if (!box_hit<MODE>(r, F3(S.rootMin), F3(S.rootMax), tn)) return false; // Partition.cpp:36 on the root
+	if (S.rootRef == REF_NONE || !box_hit<MODE_EXACT>(r, F3(S.rootMin), F3(S.rootMax), tn)) return false; // Partition.cpp:36 on the root
 	uint32_t stkRef[STACK_MAX];
 	float stkT[STACK_MAX];
 	int sp = 0;
@@ -227,8 +233,8 @@ __device__ __forceinline__ bool traverse(const DScene& S, const RayCtx& r, float
 			const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
 			const uint32_t lref = __float_as_uint(q0.w), rref = __float_as_uint(q1.w);
 			float tl, tr;
-			const bool hl = (lref != REF_NONE) && box_hit<MODE>(r, F3(q0), F3(q1), tl) && !(tl > tcull);
-			const bool hr = (rref != REF_NONE) && box_hit<MODE>(r, F3(q2), F3(q3), tr) && !(tr > tcull);
+			const bool hl = (lref != REF_NONE) && box_hit<MODE_EXACT>(r, F3(q0), F3(q1), tl) && !(tl > tcull);
+			const bool hr = (rref != REF_NONE) && box_hit<MODE_EXACT>(r, F3(q2), F3(q3), tr) && !(tr > tcull);
 			if (hl && hr) {
 				const bool leftFirst = tl <= tr;
 				stkRef[sp] = leftFirst ? rref : lref;
@@ -249,10 +255,10 @@ __device__ __forceinline__ bool traverse(const DScene& S, const RayCtx& r, float
 				float dist;
 				if (pr & PRIM_SPHERE) {
 					f3 dummy;
-					dist = sphere_hit<false>(r, S.spheres + (size_t)(pr & ~PRIM_SPHERE) * 10, dummy);
+					dist = sphere_hit<false>(r, S.spheres + (size_t)(pr & ~PRIM_SPHERE) * SPHERE_F4, dummy);
 				}
 				else {
-					dist = tri_hit<MODE>(r, S.tris + (size_t)pr * 4, tcull);
+					dist = tri_hit<MODE_EXACT>(r, S.tris + (size_t)pr * 4, tcull);
 				}
 				if (dist >= 0.0f && !isinf(dist)) {
 					if (ANY) {
@@ -277,22 +283,146 @@ __device__ __forceinline__ bool traverse(const DScene& S, const RayCtx& r, float
 	}
 }
 
+// ---- primitive hierarchy + membership check (MODE_EXACT / MODE_FAST) -----------------------------------------------------
+// Conservative slab test for the hierarchy's own (padded) boxes: reciprocal multiply plus slack, never rejects a box the
+// exact arithmetic would accept.  tnear = entry parameter.
+__device__ __forceinline__ bool box_filter(const RayCtx& r, const float4& lo, const float4& hi, float tcull, float& tnear) {
+	const float t1 = (lo.x - r.o.x) * r.ie.x, t2 = (hi.x - r.o.x) * r.ie.x;
+	const float t3 = (lo.y - r.o.y) * r.ie.y, t4 = (hi.y - r.o.y) * r.ie.y;
+	const float t5 = (lo.z - r.o.z) * r.ie.z, t6 = (hi.z - r.o.z) * r.ie.z;
+	const float tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+	const float tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+	tnear = tmin;
+	const float slack = 4e-6f * fmaxf(fabsf(tmin), fabsf(tmax)) + 1e-30f;
+	return (tmin <= tmax + slack) && (tmax >= 0.0f) && !(tmin > tcull);
+}
+
+// Is the primitive held by a reference leaf whose box the ray hits?  Returns the visiting rank of the first such
+// (leaf, primitive) entry, or REF_NONE.  AABB::intersect is evaluated exactly (IEEE division, AABB.cpp:53-72).
+__device__ __forceinline__ uint32_t membership(const DScene& S, const RayCtx& r, uint32_t ofs, uint32_t cnt) {
+	const float4* e = S.memb + (size_t)ofs * 2;
+	for (uint32_t k = 0; k < cnt; ++k) {
+		const float4 lo = e[2 * k], hi = e[2 * k + 1];
+		float tn;
+		if (box_hit<MODE_EXACT>(r, F3(lo), F3(hi), tn)) return __float_as_uint(lo.w);
+	}
+	return REF_NONE;
+}
+
+#define STACK_LDS 24
+
+struct LdsStack {
+	uint32_t* lds;   // [STACK_LDS][BLOCK], this thread's column pre-offset
+	uint32_t* ovf;   // [level][global thread], this thread's column pre-offset (may be NULL when the tree is shallow)
+	uint32_t ovfStride;
+	__device__ __forceinline__ void push(int sp, uint32_t v) {
+		if (sp < STACK_LDS) lds[sp * BLOCK] = v;
+		else ovf[(size_t)(sp - STACK_LDS) * ovfStride] = v;
+	}
+	__device__ __forceinline__ uint32_t pop(int sp) {
+		if (sp < STACK_LDS) return lds[sp * BLOCK];
+		return ovf[(size_t)(sp - STACK_LDS) * ovfStride];
+	}
+};
+
+template <int MODE, bool ANY>
+__device__ __forceinline__ bool traverse_bvh(const DScene& S, const RayCtx& r, float limit, Hit& best, LdsStack& stk) {
+	best.dist = __builtin_inff();
+	best.ref = REF_NONE;
+	best.pos = 0xffffffffu;
+	float tcull = ANY ? (limit * r.invLen * 1.0001f + 1e-5f) : __builtin_inff();
+	uint32_t cur = S.bvhRoot;
+	{
+		float tn;
+		const float4 lo = make_float4(S.bvhMin[0], S.bvhMin[1], S.bvhMin[2], 0.0f), hi = make_float4(S.bvhMax[0], S.bvhMax[1], S.bvhMax[2], 0.0f);
+		if (cur == BVH_DONE || !box_filter(r, lo, hi, tcull, tn)) return false;
+	}
+	int sp = 0;
+	for (;;) {
+		// descend through interior nodes
+		while (!(cur & BVH_LEAF)) {
+			const float4* nd = S.bvh + (size_t)cur * 4;
+			const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+			const uint32_t lref = __float_as_uint(q0.w), rref = __float_as_uint(q1.w);
+			float tl, tr;
+			const bool hl = box_filter(r, q0, q1, tcull, tl);
+			const bool hr = box_filter(r, q2, q3, tcull, tr);
+			if (hl && hr) {
+				const bool leftFirst = tl <= tr;
+				stk.push(sp, leftFirst ? rref : lref);
+				++sp;
+				cur = leftFirst ? lref : rref;
+			}
+			else if (hl) cur = lref;
+			else if (hr) cur = rref;
+			else if (sp > 0) cur = stk.pop(--sp);
+			else cur = BVH_DONE;
+		}
+		if (cur == BVH_DONE) break;
+		// leaf: 1..8 consecutive records of one kind
+		const uint32_t first = cur & BVH_FIRST_MASK;
+		const uint32_t cnt = ((cur >> BVH_COUNT_SHIFT) & 7u) + 1u;
+		const bool sph = (cur & BVH_SPHERES) != 0;
+		for (uint32_t k = 0; k < cnt; ++k) {
+			const uint32_t idx = first + k;
+			float dist;
+			if (sph) {
+				f3 dummy;
+				dist = sphere_hit<false>(r, S.spheres + (size_t)idx * SPHERE_F4, dummy);
+			}
+			else {
+				dist = tri_hit<MODE>(r, S.tris + (size_t)idx * 4, tcull);
+			}
+			if (!(dist >= 0.0f) || isinf(dist)) continue;
+			const uint32_t ref = sph ? (PRIM_SPHERE | idx) : idx;
+			if (ANY) {
+				if (dist < limit) {
+					uint32_t pos = 0;
+					if (MODE == MODE_EXACT) {
+						const uint4 info = sph ? S.sphInfo[idx] : S.triInfo[idx];
+						pos = membership(S, r, info.z, info.w);
+					}
+					if (pos != REF_NONE) { best.dist = dist; best.ref = ref; best.pos = pos; return true; }
+				}
+			}
+			else if (dist < best.dist || (dist == best.dist && ref != best.ref)) {
+				uint32_t pos = 0;
+				if (MODE == MODE_EXACT) {
+					const uint4 info = sph ? S.sphInfo[idx] : S.triInfo[idx];
+					pos = membership(S, r, info.z, info.w);
+				}
+				// Partition.h:33 (first in a leaf wins), Partition.cpp:47 (left subtree wins) == lower visiting rank wins
+				if (pos != REF_NONE && (dist < best.dist || pos < best.pos)) {
+					best.dist = dist;
+					best.ref = ref;
+					best.pos = pos;
+					tcull = dist * r.invLen * 1.0001f + 1e-5f;
+				}
+			}
+		}
+		if (sp == 0) break;
+		cur = stk.pop(--sp);
+	}
+	return best.ref != REF_NONE;
+}
+
+template <int MODE, bool ANY>
+__device__ __forceinline__ bool trace_ray(const DScene& S, const RayCtx& r, float limit, Hit& best, LdsStack& stk) {
+	if (MODE == MODE_REFWALK) return traverse_ref<ANY>(S, r, limit, best);
+	return traverse_bvh<MODE, ANY>(S, r, limit, best, stk);
+}
+
 // Intersection::intersectNormal of the winning primitive (normalised by the Intersection ctor, SceneObjects.hpp:39)
 __device__ __forceinline__ f3 hit_normal(const DScene& S, const RayCtx& r, uint32_t ref) {
 	if (ref & PRIM_SPHERE) {
 		f3 n;
-		sphere_hit<true>(r, S.spheres + (size_t)(ref & ~PRIM_SPHERE) * 10, n);
+		sphere_hit<true>(r, S.spheres + (size_t)(ref & ~PRIM_SPHERE) * SPHERE_F4, n);
 		return normalize3(n);
 	}
 	return normalize3(F3(S.tris[(size_t)ref * 4]));
 }
-__device__ __forceinline__ uint32_t prim_id_of(const DScene& S, uint32_t ref) {
-	if (ref & PRIM_SPHERE) return __float_as_uint(S.spheres[(size_t)(ref & ~PRIM_SPHERE) * 10 + 9].x);
-	return __float_as_uint(S.tris[(size_t)ref * 4 + 2].w);
-}
-__device__ __forceinline__ uint32_t material_of(const DScene& S, uint32_t ref) {
-	if (ref & PRIM_SPHERE) return __float_as_uint(S.spheres[(size_t)(ref & ~PRIM_SPHERE) * 10 + 9].y);
-	return __float_as_uint(S.tris[(size_t)ref * 4 + 3].w);
+__device__ __forceinline__ uint4 info_of(const DScene& S, uint32_t ref) {
+	return (ref & PRIM_SPHERE) ? S.sphInfo[ref & ~PRIM_SPHERE] : S.triInfo[ref];
 }
 
 // Camera::createRayToPixel(j + 0.5, i + 0.5, w, h) (Camera.cpp:15-24; basis and tan precomputed on the host with
@@ -347,6 +477,11 @@ __device__ __forceinline__ uint32_t next_chunk(uint32_t* cursor) {
 // ---- depth 0: generate + trace primary rays -----------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_primary(DScene S, DFrame F, uint8_t* __restrict__ out, int launch) {
+	__shared__ uint32_t s_stack[MODE == MODE_REFWALK ? 1 : STACK_LDS * BLOCK];
+	LdsStack stk;
+	stk.lds = s_stack + (MODE == MODE_REFWALK ? 0 : threadIdx.x);
+	stk.ovf = S.ovf ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
+	stk.ovfStride = S.ovfStride;
 	for (;;) {
 		const uint32_t base = next_chunk(F.counters + CTR_CURSOR(launch));
 		if (base >= F.nSlots) return;
@@ -360,7 +495,7 @@ __global__ __launch_bounds__(BLOCK) void k_primary(DScene S, DFrame F, uint8_t* 
 		if (live) {
 			primary_ray(S, px, py, F.width, F.height, o, d);
 			r = make_ray(o, d);
-			traverse<MODE, false>(S, r, 0.0f, h);
+			trace_ray<MODE, false>(S, r, 0.0f, h, stk);
 		}
 		const bool hit = live && h.ref != REF_NONE;
 		if (live && (!hit || F.debug == D_PRIMARY_MAP)) {
@@ -385,6 +520,11 @@ __global__ __launch_bounds__(BLOCK) void k_primary(DScene S, DFrame F, uint8_t* 
 // ---- depth >= 1: trace queued reflection rays ---------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_trace(DScene S, DFrame F, int depth, int launch) {
+	__shared__ uint32_t s_stack[MODE == MODE_REFWALK ? 1 : STACK_LDS * BLOCK];
+	LdsStack stk;
+	stk.lds = s_stack + (MODE == MODE_REFWALK ? 0 : threadIdx.x);
+	stk.ovf = S.ovf ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
+	stk.ovfStride = S.ovfStride;
 	const uint32_t n = F.counters[CTR_NRAYS(depth)];
 	const size_t half = (size_t)(depth & 1) * F.nSlots;
 	for (;;) {
@@ -400,7 +540,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DScene S, DFrame F, int depth, 
 			ro = F.rayO[half + i];
 			rd = F.rayD[half + i];
 			r = make_ray(F3(ro), F3(rd));
-			traverse<MODE, false>(S, r, 0.0f, h);
+			trace_ray<MODE, false>(S, r, 0.0f, h, stk);
 		}
 		const bool hit = live && h.ref != REF_NONE;
 		const uint32_t q = queue_push(F.counters + CTR_NHITS(depth), hit);
@@ -416,6 +556,11 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DScene S, DFrame F, int depth, 
 // ---- shade the hits of one depth: lights, shadow rays, spawn the reflection ray -------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, DFrame F, int depth, int launch) {
+	__shared__ uint32_t s_stack[MODE == MODE_REFWALK ? 1 : STACK_LDS * BLOCK];
+	LdsStack stk;
+	stk.lds = s_stack + (MODE == MODE_REFWALK ? 0 : threadIdx.x);
+	stk.ovf = S.ovf ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
+	stk.ovfStride = S.ovfStride;
 	const uint32_t n = F.counters[CTR_NHITS(depth)];
 	const size_t nextHalf = (size_t)((depth + 1) & 1) * F.nSlots;
 	const bool spawn = (F.features & F_REFLECTIONS) && (depth + 1 <= S.maxDepth) && F.debug != D_PRIMARY_MAP; // main.cpp:177,189
@@ -432,7 +577,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, DFrame F, int depth, 
 			slot = __float_as_uint(ho.w);
 			const float dist = hd.w;
 			const uint32_t ref = __float_as_uint(hn.w);
-			const float4* mat = S.materials + (size_t)material_of(S, ref) * 4;
+			const float4* mat = S.materials + (size_t)info_of(S, ref).y * 4;
 			const float4 mDiff = mat[0], mSpec = mat[1], mEmis = mat[2], mAmb = mat[3];
 			const float shininess = mDiff.w;
 			P = o + normalize3(d) * dist;                                   // Camera.cpp:26-28
@@ -458,11 +603,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, DFrame F, int depth, 
 				if (F.features & F_SHADOWS) {
 					const RayCtx sr = make_ray(P, Ln);
 					if (F.debug == D_SHADOW_MAP) {
-						traverse<MODE, false>(S, sr, 0.0f, occ);
+						trace_ray<MODE, false>(S, sr, 0.0f, occ, stk);
 						lit = (occ.ref == REF_NONE) || (occ.dist >= lenL);
 					}
 					else {
-						lit = !traverse<MODE, true>(S, sr, lenL, occ);
+						lit = !trace_ray<MODE, true>(S, sr, lenL, occ, stk);
 					}
 				}
 				if (lit) {
@@ -481,7 +626,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, DFrame F, int depth, 
 					}
 				}
 				else if (F.debug == D_SHADOW_MAP) {
-					const float4* om = S.materials + (size_t)material_of(S, occ.ref) * 4;
+					const float4* om = S.materials + (size_t)info_of(S, occ.ref).y * 4;
 					sum = sum + F3(om[0]);                                  // :250-252
 				}
 			}
@@ -537,13 +682,18 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DFrame F, uint8_t* __restrict
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_trace_list(DScene S, uint64_t n, const float* __restrict__ o3, const float* __restrict__ d3,
                                                       int32_t* __restrict__ primId, float* __restrict__ dist, float* __restrict__ normal) {
+	__shared__ uint32_t s_stack[MODE == MODE_REFWALK ? 1 : STACK_LDS * BLOCK];
+	LdsStack stk;
+	stk.lds = s_stack + (MODE == MODE_REFWALK ? 0 : threadIdx.x);
+	stk.ovf = S.ovf ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
+	stk.ovfStride = S.ovfStride;
 	for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
 		const f3 o = F3(o3 + 3 * i), d = F3(d3 + 3 * i);
 		const RayCtx r = make_ray(o, d);
 		Hit h;
-		traverse<MODE, false>(S, r, 0.0f, h);
+		trace_ray<MODE, false>(S, r, 0.0f, h, stk);
 		if (h.ref != REF_NONE) {
-			primId[i] = (int32_t)prim_id_of(S, h.ref);
+			primId[i] = (int32_t)info_of(S, h.ref).x;
 			dist[i] = h.dist;
 			if (normal) {
 				const f3 nn = hit_normal(S, r, h.ref);
@@ -560,14 +710,19 @@ __global__ __launch_bounds__(BLOCK) void k_trace_list(DScene S, uint64_t n, cons
 
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_primary_ids(DScene S, uint32_t width, uint32_t height, int32_t* __restrict__ primId, float* __restrict__ dist) {
+	__shared__ uint32_t s_stack[MODE == MODE_REFWALK ? 1 : STACK_LDS * BLOCK];
+	LdsStack stk;
+	stk.lds = s_stack + (MODE == MODE_REFWALK ? 0 : threadIdx.x);
+	stk.ovf = S.ovf ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
+	stk.ovfStride = S.ovfStride;
 	const uint64_t n = (uint64_t)width * height;
 	for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
 		f3 o, d;
 		primary_ray(S, (uint32_t)(i % width), (uint32_t)(i / width), width, height, o, d);
 		const RayCtx r = make_ray(o, d);
 		Hit h;
-		traverse<MODE, false>(S, r, 0.0f, h);
-		primId[i] = h.ref != REF_NONE ? (int32_t)prim_id_of(S, h.ref) : -1;
+		trace_ray<MODE, false>(S, r, 0.0f, h, stk);
+		primId[i] = h.ref != REF_NONE ? (int32_t)info_of(S, h.ref).x : -1;
 		dist[i] = h.ref != REF_NONE ? h.dist : __builtin_inff();
 	}
 }

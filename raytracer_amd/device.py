@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import (DEBUG_NONE, F_ALL, TRACE_EXACT, TRACE_FAST, RenderParams, Stats, make_params)  # noqa: F401
+from ._capi import (DEBUG_NONE, F_ALL, TRACE_EXACT, TRACE_FAST, TRACE_REFWALK, RenderParams, Stats, make_params)  # noqa: F401
 
 
 class MirtError(RuntimeError):
