@@ -182,6 +182,16 @@ size_t mirt_tile_buffer_bytes(const mirt_render_params* params);
 /* Counters of the most recent mirt_render_device call on this scene (synchronises hip_stream). */
 int mirt_get_stats(mirt_scene* scene, void* hip_stream, mirt_stats* stats);
 
+/* Facts about the uploaded scene (sizes of the device structures, for reports and tests).  No reference counterpart;
+ * the reference prints uninitialised object counters (Scene.h:47, main.cpp:337-342). */
+#define MIRT_Q_HIERARCHY_DEPTH 0u  /* depth of the primitive hierarchy */
+#define MIRT_Q_HIERARCHY_NODES 1u  /* its 64-byte nodes */
+#define MIRT_Q_TREE_NESTED 2u      /* 1 if every Partition child box lies inside its parent's (EXACT/FAST usable) */
+#define MIRT_Q_MEMBERSHIP_ENTRIES 3u /* (leaf, primitive) pairs of the Partition tree */
+#define MIRT_Q_DEVICE_BYTES 4u     /* bytes of HBM held by the scene (without frame workspaces) */
+#define MIRT_Q_TREE_WIDE_DEPTH 5u  /* depth of the Partition tree after single-child chains are skipped */
+int mirt_scene_query(mirt_scene* scene, uint32_t what, uint64_t* value_out);
+
 /* Per-kernel timing of the frames rendered on this scene.  After mirt_set_profiling(scene, 1) every kernel launch of a
  * frame is bracketed by HIP events recorded on the frame's own stream; mirt_get_launch_times synchronises that stream and
  * returns the duration of each launch of the most recent frame in issue order: primary, shade(0), trace(1), shade(1), ...,

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmirt.so")
+LIB_PATH = os.environ.get("MIRT_LIB") or os.path.join(HERE, "libmirt.so")  # MIRT_LIB: A/B builds while tuning
 
 MIRT_NO_CHILD = 0x7FFFFFFF
 MIRT_LEAF_FLAG = 0x80000000
@@ -90,6 +90,7 @@ SYMBOLS = [
     ("mirt_render_device", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_size_t, C.c_void_p]),
     ("mirt_tile_buffer_bytes", C.c_size_t, [C.POINTER(RenderParams)]),
     ("mirt_get_stats", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
+    ("mirt_scene_query", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("mirt_set_profiling", C.c_int, [C.c_void_p, C.c_int]),
     ("mirt_get_launch_times", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     ("mirt_assemble_tiles", C.c_int, [C.c_int, C.POINTER(RenderParams), C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

@@ -79,6 +79,7 @@ struct mirt_scene {
 	DevBuf nodes, leafs, bvh, memb, tris, triInfo, spheres, sphInfo, materials, lights, ovf;
 	bool nested = true;      // reference boxes nested: the primitive hierarchy may be used
 	uint32_t bvhDepth = 0;
+	bool deepBvh = false;    // hierarchy deeper than the LDS part of the traversal stack
 	Workspace ws;
 	hipStream_t stream = nullptr; // used by the synchronous entry points
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -258,22 +259,22 @@ void mark(mirt_scene* s, hipStream_t st, int kind) {
 	s->nLaunches++;
 }
 
-template <int MODE>
+template <int MODE, bool OVF>
 void launch_frame(mirt_scene* s, const DFrame& F, uint8_t* out, hipStream_t st) {
 	const int grid = s->numCUs * GRID_BLOCKS_PER_CU;
 	int launch = 0;
 	s->nLaunches = 0;
 	mark(s, st, -1);
-	hipLaunchKernelGGL(k_primary<MODE>, dim3(grid), dim3(BLOCK), 0, st, s->ds, F, out, launch++);
+	hipLaunchKernelGGL((k_primary<MODE, OVF>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, out, launch++);
 	mark(s, st, MIRT_K_PRIMARY);
 	if (F.debug != D_PRIMARY_MAP) {
 		const int last = (F.features & F_REFLECTIONS) ? s->maxDepth : 0;
 		for (int depth = 0; depth <= last; ++depth) {
 			if (depth > 0) {
-				hipLaunchKernelGGL(k_trace<MODE>, dim3(grid), dim3(BLOCK), 0, st, s->ds, F, depth, launch++);
+				hipLaunchKernelGGL((k_trace<MODE, OVF>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, depth, launch++);
 				mark(s, st, MIRT_K_TRACE);
 			}
-			hipLaunchKernelGGL(k_shade<MODE>, dim3(grid), dim3(BLOCK), 0, st, s->ds, F, depth, launch++);
+			hipLaunchKernelGGL((k_shade<MODE, OVF>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, depth, launch++);
 			mark(s, st, MIRT_K_SHADE);
 		}
 		hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(BLOCK), 0, st, F, out);
@@ -327,9 +328,15 @@ int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 	HIPCHK(hipEventRecord(s->ev0, st));
 	HIPCHK(hipMemsetAsync(w.counters.p, 0, CTR_COUNT * 4, st));
 	switch (effective_mode(s, p->trace_mode)) {
-	case MODE_FAST: launch_frame<MODE_FAST>(s, F, (uint8_t*)d_out, st); break;
-	case MODE_REFWALK: launch_frame<MODE_REFWALK>(s, F, (uint8_t*)d_out, st); break;
-	default: launch_frame<MODE_EXACT>(s, F, (uint8_t*)d_out, st); break;
+	case MODE_FAST:
+		if (s->deepBvh) launch_frame<MODE_FAST, true>(s, F, (uint8_t*)d_out, st);
+		else launch_frame<MODE_FAST, false>(s, F, (uint8_t*)d_out, st);
+		break;
+	case MODE_REFWALK: launch_frame<MODE_REFWALK, false>(s, F, (uint8_t*)d_out, st); break;
+	default:
+		if (s->deepBvh) launch_frame<MODE_EXACT, true>(s, F, (uint8_t*)d_out, st);
+		else launch_frame<MODE_EXACT, false>(s, F, (uint8_t*)d_out, st);
+		break;
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(s->ev1, st));
@@ -646,7 +653,8 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	if (!e) e = upload(s->lights, lights.data(), lights.size() * 4);
 	ds.ovf = nullptr;
 	ds.ovfStride = (uint32_t)s->numCUs * GRID_BLOCKS_PER_CU * BLOCK;
-	if (!e && bb.maxDepth + 1 > STACK_LDS) {
+	s->deepBvh = bb.maxDepth + 1 > STACK_LDS;
+	if (!e && s->deepBvh) {
 		e = s->ovf.ensure((size_t)(bb.maxDepth + 1 - STACK_LDS) * ds.ovfStride * 4);
 		ds.ovf = (uint32_t*)s->ovf.p;
 	}
@@ -699,6 +707,23 @@ size_t mirt_tile_buffer_bytes(const mirt_render_params* p) {
 int mirt_render_device(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t d_out_bytes, void* hip_stream) {
 	if (!p) return fail(MIRT_E_INVALID, "render params are NULL");
 	return render_async(s, p, d_out, d_out_bytes, (hipStream_t)hip_stream, packed_layout(p));
+}
+
+int mirt_scene_query(mirt_scene* s, uint32_t what, uint64_t* v) {
+	if (!s || !v) return fail(MIRT_E_INVALID, "NULL argument");
+	switch (what) {
+	case MIRT_Q_HIERARCHY_DEPTH: *v = s->bvhDepth; break;
+	case MIRT_Q_HIERARCHY_NODES: *v = s->bvh.bytes / 64; break;
+	case MIRT_Q_TREE_NESTED: *v = s->nested ? 1 : 0; break;
+	case MIRT_Q_MEMBERSHIP_ENTRIES: *v = s->memb.bytes / 32; break;
+	case MIRT_Q_DEVICE_BYTES:
+		*v = s->nodes.bytes + s->leafs.bytes + s->bvh.bytes + s->memb.bytes + s->tris.bytes + s->triInfo.bytes + s->spheres.bytes + s->sphInfo.bytes +
+		     s->materials.bytes + s->lights.bytes + s->ovf.bytes;
+		break;
+	case MIRT_Q_TREE_WIDE_DEPTH: *v = s->wideDepth; break;
+	default: return fail(MIRT_E_INVALID, "unknown query %u", what);
+	}
+	return MIRT_OK;
 }
 
 int mirt_set_profiling(mirt_scene* s, int enabled) {
@@ -795,12 +820,11 @@ int mirt_trace_rays(mirt_scene* s, uint32_t trace_mode, uint64_t n, const float*
 	if (!e) {
 		const int grid = (int)((n + BLOCK - 1) / BLOCK < (uint64_t)s->numCUs * GRID_BLOCKS_PER_CU ? (n + BLOCK - 1) / BLOCK : (uint64_t)s->numCUs * GRID_BLOCKS_PER_CU);
 		const int mode = effective_mode(s, trace_mode);
-		if (mode == MODE_FAST)
-			hipLaunchKernelGGL(k_trace_list<MODE_FAST>, dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, n, (const float*)o.p, (const float*)d.p, (int32_t*)id.p, (float*)dist.p, (float*)nrm.p);
-		else if (mode == MODE_REFWALK)
-			hipLaunchKernelGGL(k_trace_list<MODE_REFWALK>, dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, n, (const float*)o.p, (const float*)d.p, (int32_t*)id.p, (float*)dist.p, (float*)nrm.p);
-		else
-			hipLaunchKernelGGL(k_trace_list<MODE_EXACT>, dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, n, (const float*)o.p, (const float*)d.p, (int32_t*)id.p, (float*)dist.p, (float*)nrm.p);
+#define LAUNCH_LIST(M, O) hipLaunchKernelGGL((k_trace_list<M, O>), dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, n, (const float*)o.p, (const float*)d.p, (int32_t*)id.p, (float*)dist.p, (float*)nrm.p)
+		if (mode == MODE_REFWALK) LAUNCH_LIST(MODE_REFWALK, false);
+		else if (mode == MODE_FAST) { if (s->deepBvh) LAUNCH_LIST(MODE_FAST, true); else LAUNCH_LIST(MODE_FAST, false); }
+		else { if (s->deepBvh) LAUNCH_LIST(MODE_EXACT, true); else LAUNCH_LIST(MODE_EXACT, false); }
+#undef LAUNCH_LIST
 		hipError_t he = hipGetLastError();
 		if (he == hipSuccess) he = hipStreamSynchronize(s->stream);
 		if (he == hipSuccess) he = hipMemcpy(prim_id_out, id.p, n * 4, hipMemcpyDeviceToHost);
@@ -824,12 +848,11 @@ int mirt_trace_primary_ids(mirt_scene* s, uint32_t trace_mode, uint32_t width, u
 	if (!e) {
 		const int grid = (int)((n + BLOCK - 1) / BLOCK < (uint64_t)s->numCUs * GRID_BLOCKS_PER_CU ? (n + BLOCK - 1) / BLOCK : (uint64_t)s->numCUs * GRID_BLOCKS_PER_CU);
 		const int mode = effective_mode(s, trace_mode);
-		if (mode == MODE_FAST)
-			hipLaunchKernelGGL(k_primary_ids<MODE_FAST>, dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, width, height, (int32_t*)id.p, (float*)dist.p);
-		else if (mode == MODE_REFWALK)
-			hipLaunchKernelGGL(k_primary_ids<MODE_REFWALK>, dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, width, height, (int32_t*)id.p, (float*)dist.p);
-		else
-			hipLaunchKernelGGL(k_primary_ids<MODE_EXACT>, dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, width, height, (int32_t*)id.p, (float*)dist.p);
+#define LAUNCH_IDS(M, O) hipLaunchKernelGGL((k_primary_ids<M, O>), dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, width, height, (int32_t*)id.p, (float*)dist.p)
+		if (mode == MODE_REFWALK) LAUNCH_IDS(MODE_REFWALK, false);
+		else if (mode == MODE_FAST) { if (s->deepBvh) LAUNCH_IDS(MODE_FAST, true); else LAUNCH_IDS(MODE_FAST, false); }
+		else { if (s->deepBvh) LAUNCH_IDS(MODE_EXACT, true); else LAUNCH_IDS(MODE_EXACT, false); }
+#undef LAUNCH_IDS
 		hipError_t he = hipGetLastError();
 		if (he == hipSuccess) he = hipStreamSynchronize(s->stream);
 		if (he == hipSuccess) he = hipMemcpy(prim_id_out, id.p, n * 4, hipMemcpyDeviceToHost);

@@ -33,7 +33,10 @@ struct BvhNode {
 
 struct BvhBuilder {
 	static const int BINS = 16;
-	static const uint32_t LEAF_MAX = 4;
+#ifndef MIRT_LEAF_MAX
+#define MIRT_LEAF_MAX 4
+#endif
+	static const uint32_t LEAF_MAX = MIRT_LEAF_MAX;
 	static const int SAH_DEPTH = 28; // below this depth splits are balanced medians, which bounds the total depth
 
 	std::vector<BvhPrim> prims; // reordered in place: leaf ranges are contiguous

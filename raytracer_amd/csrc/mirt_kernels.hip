@@ -36,6 +36,10 @@
 #define MODE_FAST 1
 #define MODE_REFWALK 2
 
+#ifndef MIRT_BOX_FMA
+#define MIRT_BOX_FMA 0
+#endif
+
 struct f3 {
 	float x, y, z;
 };
@@ -68,6 +72,10 @@ struct RayCtx {
 	f3 e;      // direction with AABB.cpp:53-58's substitution: |d| < 1e-5 -> +1e-5
 	f3 ie;     // 1/d for the hierarchy's conservative box filter
 	float invLen; // 1/|d|, used only for conservative culling
+#if MIRT_BOX_FMA
+	f3 oie;    // o * ie
+	float ferr; // bound on the rounding error of the fused slab parameters
+#endif
 };
 
 __device__ __forceinline__ RayCtx make_ray(f3 o, f3 d) {
@@ -83,6 +91,11 @@ __device__ __forceinline__ RayCtx make_ray(f3 o, f3 d) {
 	const float sz = fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z;
 	r.ie = F3(1.0f / sx, 1.0f / sy, 1.0f / sz);
 	r.invLen = inv_sqrt(dot3(d, d));
+#if MIRT_BOX_FMA
+	r.oie = r.o * r.ie;
+	// |fl(o*ie) - o*ie| <= 2^-24 |o*ie| per axis, the FMA adds half an ulp of the (smaller) result: 2^-22 max|o*ie| covers both boxes' planes
+	r.ferr = 2.4e-7f * fmaxf(fmaxf(fabsf(r.oie.x), fabsf(r.oie.y)), fabsf(r.oie.z)) + 1e-30f;
+#endif
 	return r;
 }
 
@@ -287,14 +300,26 @@ __device__ __noinline__ bool traverse_ref(const DScene& S, const RayCtx& r, floa
 // Conservative slab test for the hierarchy's own (padded) boxes: reciprocal multiply plus slack, never rejects a box the
 // exact arithmetic would accept.  tnear = entry parameter.
 __device__ __forceinline__ bool box_filter(const RayCtx& r, const float4& lo, const float4& hi, float tcull, float& tnear) {
+#if MIRT_BOX_FMA
+	// t = lo*ie - o*ie in one FMA; its absolute error is bounded by r.ferr (set in make_ray), which widens the accept test
+	const float t1 = __builtin_fmaf(lo.x, r.ie.x, -r.oie.x), t2 = __builtin_fmaf(hi.x, r.ie.x, -r.oie.x);
+	const float t3 = __builtin_fmaf(lo.y, r.ie.y, -r.oie.y), t4 = __builtin_fmaf(hi.y, r.ie.y, -r.oie.y);
+	const float t5 = __builtin_fmaf(lo.z, r.ie.z, -r.oie.z), t6 = __builtin_fmaf(hi.z, r.ie.z, -r.oie.z);
+#else
 	const float t1 = (lo.x - r.o.x) * r.ie.x, t2 = (hi.x - r.o.x) * r.ie.x;
 	const float t3 = (lo.y - r.o.y) * r.ie.y, t4 = (hi.y - r.o.y) * r.ie.y;
 	const float t5 = (lo.z - r.o.z) * r.ie.z, t6 = (hi.z - r.o.z) * r.ie.z;
+#endif
 	const float tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
 	const float tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
 	tnear = tmin;
+#if MIRT_BOX_FMA
+	const float slack = 4e-6f * fmaxf(fabsf(tmin), fabsf(tmax)) + r.ferr;
+	return (tmin <= tmax + slack) && (tmax >= -r.ferr) && !(tmin - r.ferr > tcull);
+#else
 	const float slack = 4e-6f * fmaxf(fabsf(tmin), fabsf(tmax)) + 1e-30f;
 	return (tmin <= tmax + slack) && (tmax >= 0.0f) && !(tmin > tcull);
+#endif
 }
 
 // Is the primitive held by a reference leaf whose box the ray hits?  Returns the visiting rank of the first such
@@ -309,24 +334,29 @@ __device__ __forceinline__ uint32_t membership(const DScene& S, const RayCtx& r,
 	return REF_NONE;
 }
 
-#define STACK_LDS 24
+#define STACK_LDS 32
 
+// Traversal stack: STACK_LDS entries per lane in LDS ([entry][lane]: conflict-free, no address arithmetic beyond a
+// shift).  Hierarchies deeper than that (OVF = true, chosen by the host from the built depth) keep the deeper entries in
+// a global array; the two cases are separate instantiations so that the common one contains LDS instructions only
+// (a merged pointer would turn every pop into a flat_load).
+template <bool OVF>
 struct LdsStack {
-	uint32_t* lds;   // [STACK_LDS][BLOCK], this thread's column pre-offset
-	uint32_t* ovf;   // [level][global thread], this thread's column pre-offset (may be NULL when the tree is shallow)
+	uint32_t* lds;   // this thread's column
+	uint32_t* ovf;   // [level][global thread], this thread's column
 	uint32_t ovfStride;
 	__device__ __forceinline__ void push(int sp, uint32_t v) {
-		if (sp < STACK_LDS) lds[sp * BLOCK] = v;
-		else ovf[(size_t)(sp - STACK_LDS) * ovfStride] = v;
+		if (!OVF || sp < STACK_LDS) lds[sp * BLOCK] = v;
+		else __builtin_nontemporal_store(v, ovf + (size_t)(sp - STACK_LDS) * ovfStride);
 	}
 	__device__ __forceinline__ uint32_t pop(int sp) {
-		if (sp < STACK_LDS) return lds[sp * BLOCK];
-		return ovf[(size_t)(sp - STACK_LDS) * ovfStride];
+		if (!OVF || sp < STACK_LDS) return lds[sp * BLOCK];
+		return __builtin_nontemporal_load(ovf + (size_t)(sp - STACK_LDS) * ovfStride);
 	}
 };
 
-template <int MODE, bool ANY>
-__device__ __forceinline__ bool traverse_bvh(const DScene& S, const RayCtx& r, float limit, Hit& best, LdsStack& stk) {
+template <int MODE, bool ANY, bool OVF>
+__device__ __forceinline__ bool traverse_bvh(const DScene& S, const RayCtx& r, float limit, Hit& best, LdsStack<OVF>& stk) {
 	best.dist = __builtin_inff();
 	best.ref = REF_NONE;
 	best.pos = 0xffffffffu;
@@ -406,10 +436,10 @@ __device__ __forceinline__ bool traverse_bvh(const DScene& S, const RayCtx& r, f
 	return best.ref != REF_NONE;
 }
 
-template <int MODE, bool ANY>
-__device__ __forceinline__ bool trace_ray(const DScene& S, const RayCtx& r, float limit, Hit& best, LdsStack& stk) {
+template <int MODE, bool ANY, bool OVF>
+__device__ __forceinline__ bool trace_ray(const DScene& S, const RayCtx& r, float limit, Hit& best, LdsStack<OVF>& stk) {
 	if (MODE == MODE_REFWALK) return traverse_ref<ANY>(S, r, limit, best);
-	return traverse_bvh<MODE, ANY>(S, r, limit, best, stk);
+	return traverse_bvh<MODE, ANY, OVF>(S, r, limit, best, stk);
 }
 
 // Intersection::intersectNormal of the winning primitive (normalised by the Intersection ctor, SceneObjects.hpp:39)
@@ -467,23 +497,44 @@ __device__ __forceinline__ uint32_t queue_push(uint32_t* counter, bool want) {
 	return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
-// dynamic work distribution: each wave takes the next 64 items
-__device__ __forceinline__ uint32_t next_chunk(uint32_t* cursor) {
-	uint32_t c = 0;
-	if ((threadIdx.x & 63) == 0) c = atomicAdd(cursor, 64u);
-	return __shfl(c, 0);
-}
+// Work distribution: a wave owns GRAB consecutive 64-item chunks at a time.  Its first batch is static (wave index),
+// later batches come from one atomic cursor per launch -- one atomic per GRAB*64 items keeps the cursor word far
+// below the ~88 atomics/us a single address sustains.
+template <int GRAB>
+struct Dealer {
+	uint32_t* cursor;
+	uint32_t cb, ce, stride0;
+	__device__ __forceinline__ Dealer(uint32_t* c) : cursor(c) {
+		const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
+		stride0 = gridDim.x * (BLOCK / WAVE) * (WAVE * GRAB);
+		cb = wave * (WAVE * GRAB);
+		ce = cb + WAVE * GRAB;
+	}
+	// base of the next 64-item chunk (>= n means: no more work)
+	__device__ __forceinline__ uint32_t next() {
+		if (cb >= ce) {
+			uint32_t c = 0;
+			if ((threadIdx.x & 63) == 0) c = atomicAdd(cursor, (uint32_t)(WAVE * GRAB));
+			cb = __builtin_amdgcn_readfirstlane(c) + stride0;
+			ce = cb + WAVE * GRAB;
+		}
+		const uint32_t b = cb;
+		cb += WAVE;
+		return b;
+	}
+};
 
 // ---- depth 0: generate + trace primary rays -----------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool OVF>
 __global__ __launch_bounds__(BLOCK) void k_primary(DScene S, DFrame F, uint8_t* __restrict__ out, int launch) {
 	__shared__ uint32_t s_stack[MODE == MODE_REFWALK ? 1 : STACK_LDS * BLOCK];
-	LdsStack stk;
+	LdsStack<OVF> stk;
 	stk.lds = s_stack + (MODE == MODE_REFWALK ? 0 : threadIdx.x);
-	stk.ovf = S.ovf ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
+	stk.ovf = OVF ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
 	stk.ovfStride = S.ovfStride;
+	Dealer<4> deal(F.counters + CTR_CURSOR(launch));
 	for (;;) {
-		const uint32_t base = next_chunk(F.counters + CTR_CURSOR(launch));
+		const uint32_t base = deal.next();
 		if (base >= F.nSlots) return;
 		const uint32_t slot = base + (threadIdx.x & 63);
 		uint32_t px, py, inTile;
@@ -495,7 +546,7 @@ __global__ __launch_bounds__(BLOCK) void k_primary(DScene S, DFrame F, uint8_t* 
 		if (live) {
 			primary_ray(S, px, py, F.width, F.height, o, d);
 			r = make_ray(o, d);
-			trace_ray<MODE, false>(S, r, 0.0f, h, stk);
+			trace_ray<MODE, false, OVF>(S, r, 0.0f, h, stk);
 		}
 		const bool hit = live && h.ref != REF_NONE;
 		if (live && (!hit || F.debug == D_PRIMARY_MAP)) {
@@ -518,17 +569,18 @@ __global__ __launch_bounds__(BLOCK) void k_primary(DScene S, DFrame F, uint8_t* 
 }
 
 // ---- depth >= 1: trace queued reflection rays ---------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool OVF>
 __global__ __launch_bounds__(BLOCK) void k_trace(DScene S, DFrame F, int depth, int launch) {
 	__shared__ uint32_t s_stack[MODE == MODE_REFWALK ? 1 : STACK_LDS * BLOCK];
-	LdsStack stk;
+	LdsStack<OVF> stk;
 	stk.lds = s_stack + (MODE == MODE_REFWALK ? 0 : threadIdx.x);
-	stk.ovf = S.ovf ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
+	stk.ovf = OVF ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
 	stk.ovfStride = S.ovfStride;
 	const uint32_t n = F.counters[CTR_NRAYS(depth)];
 	const size_t half = (size_t)(depth & 1) * F.nSlots;
+	Dealer<1> deal(F.counters + CTR_CURSOR(launch));
 	for (;;) {
-		const uint32_t base = next_chunk(F.counters + CTR_CURSOR(launch));
+		const uint32_t base = deal.next();
 		if (base >= n) return;
 		const uint32_t i = base + (threadIdx.x & 63);
 		const bool live = i < n;
@@ -540,7 +592,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DScene S, DFrame F, int depth, 
 			ro = F.rayO[half + i];
 			rd = F.rayD[half + i];
 			r = make_ray(F3(ro), F3(rd));
-			trace_ray<MODE, false>(S, r, 0.0f, h, stk);
+			trace_ray<MODE, false, OVF>(S, r, 0.0f, h, stk);
 		}
 		const bool hit = live && h.ref != REF_NONE;
 		const uint32_t q = queue_push(F.counters + CTR_NHITS(depth), hit);
@@ -554,18 +606,19 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DScene S, DFrame F, int depth, 
 }
 
 // ---- shade the hits of one depth: lights, shadow rays, spawn the reflection ray -------------------------------------
-template <int MODE>
+template <int MODE, bool OVF>
 __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, DFrame F, int depth, int launch) {
 	__shared__ uint32_t s_stack[MODE == MODE_REFWALK ? 1 : STACK_LDS * BLOCK];
-	LdsStack stk;
+	LdsStack<OVF> stk;
 	stk.lds = s_stack + (MODE == MODE_REFWALK ? 0 : threadIdx.x);
-	stk.ovf = S.ovf ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
+	stk.ovf = OVF ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
 	stk.ovfStride = S.ovfStride;
 	const uint32_t n = F.counters[CTR_NHITS(depth)];
 	const size_t nextHalf = (size_t)((depth + 1) & 1) * F.nSlots;
 	const bool spawn = (F.features & F_REFLECTIONS) && (depth + 1 <= S.maxDepth) && F.debug != D_PRIMARY_MAP; // main.cpp:177,189
+	Dealer<1> deal(F.counters + CTR_CURSOR(launch));
 	for (;;) {
-		const uint32_t base = next_chunk(F.counters + CTR_CURSOR(launch));
+		const uint32_t base = deal.next();
 		if (base >= n) return;
 		const uint32_t i = base + (threadIdx.x & 63);
 		const bool live = i < n;
@@ -603,11 +656,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, DFrame F, int depth, 
 				if (F.features & F_SHADOWS) {
 					const RayCtx sr = make_ray(P, Ln);
 					if (F.debug == D_SHADOW_MAP) {
-						trace_ray<MODE, false>(S, sr, 0.0f, occ, stk);
+						trace_ray<MODE, false, OVF>(S, sr, 0.0f, occ, stk);
 						lit = (occ.ref == REF_NONE) || (occ.dist >= lenL);
 					}
 					else {
-						lit = !trace_ray<MODE, true>(S, sr, lenL, occ, stk);
+						lit = !trace_ray<MODE, true, OVF>(S, sr, lenL, occ, stk);
 					}
 				}
 				if (lit) {
@@ -679,19 +732,19 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DFrame F, uint8_t* __restrict
 }
 
 // ---- narrow seam: closest hit for a list of rays ----------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool OVF>
 __global__ __launch_bounds__(BLOCK) void k_trace_list(DScene S, uint64_t n, const float* __restrict__ o3, const float* __restrict__ d3,
                                                       int32_t* __restrict__ primId, float* __restrict__ dist, float* __restrict__ normal) {
 	__shared__ uint32_t s_stack[MODE == MODE_REFWALK ? 1 : STACK_LDS * BLOCK];
-	LdsStack stk;
+	LdsStack<OVF> stk;
 	stk.lds = s_stack + (MODE == MODE_REFWALK ? 0 : threadIdx.x);
-	stk.ovf = S.ovf ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
+	stk.ovf = OVF ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
 	stk.ovfStride = S.ovfStride;
 	for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
 		const f3 o = F3(o3 + 3 * i), d = F3(d3 + 3 * i);
 		const RayCtx r = make_ray(o, d);
 		Hit h;
-		trace_ray<MODE, false>(S, r, 0.0f, h, stk);
+		trace_ray<MODE, false, OVF>(S, r, 0.0f, h, stk);
 		if (h.ref != REF_NONE) {
 			primId[i] = (int32_t)info_of(S, h.ref).x;
 			dist[i] = h.dist;
@@ -708,12 +761,12 @@ __global__ __launch_bounds__(BLOCK) void k_trace_list(DScene S, uint64_t n, cons
 	}
 }
 
-template <int MODE>
+template <int MODE, bool OVF>
 __global__ __launch_bounds__(BLOCK) void k_primary_ids(DScene S, uint32_t width, uint32_t height, int32_t* __restrict__ primId, float* __restrict__ dist) {
 	__shared__ uint32_t s_stack[MODE == MODE_REFWALK ? 1 : STACK_LDS * BLOCK];
-	LdsStack stk;
+	LdsStack<OVF> stk;
 	stk.lds = s_stack + (MODE == MODE_REFWALK ? 0 : threadIdx.x);
-	stk.ovf = S.ovf ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
+	stk.ovf = OVF ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
 	stk.ovfStride = S.ovfStride;
 	const uint64_t n = (uint64_t)width * height;
 	for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
@@ -721,7 +774,7 @@ __global__ __launch_bounds__(BLOCK) void k_primary_ids(DScene S, uint32_t width,
 		primary_ray(S, (uint32_t)(i % width), (uint32_t)(i / width), width, height, o, d);
 		const RayCtx r = make_ray(o, d);
 		Hit h;
-		trace_ray<MODE, false>(S, r, 0.0f, h, stk);
+		trace_ray<MODE, false, OVF>(S, r, 0.0f, h, stk);
 		primId[i] = h.ref != REF_NONE ? (int32_t)info_of(S, h.ref).x : -1;
 		dist[i] = h.ref != REF_NONE ? h.dist : __builtin_inff();
 	}

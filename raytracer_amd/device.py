@@ -73,6 +73,15 @@ class DeviceScene:
         _check(self.lib, self.lib.mirt_get_stats(self.h, C.c_void_p(stream_ptr), C.byref(st)))
         return st.as_dict()
 
+    def query(self):
+        names = ["hierarchy_depth", "hierarchy_nodes", "tree_nested", "membership_entries", "device_bytes", "tree_wide_depth"]
+        out = {}
+        for i, n in enumerate(names):
+            v = C.c_uint64()
+            _check(self.lib, self.lib.mirt_scene_query(self.h, i, C.byref(v)))
+            out[n] = int(v.value)
+        return out
+
     def set_profiling(self, on=True):
         _check(self.lib, self.lib.mirt_set_profiling(self.h, 1 if on else 0))
 
