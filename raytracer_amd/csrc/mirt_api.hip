@@ -55,10 +55,10 @@ struct DevBuf {
 };
 
 struct Workspace {
-	DevBuf rayO, rayD, hitO, hitD, hitN, hit0, litL, litS, depthCnt, counters, out;
+	DevBuf hitO, hitD, hitN, shRes, active, pathDepth, litL, litS, counters, out;
 	void release() {
-		rayO.release(); rayD.release(); hitO.release(); hitD.release(); hitN.release(); hit0.release();
-		litL.release(); litS.release(); depthCnt.release(); counters.release(); out.release();
+		hitO.release(); hitD.release(); hitN.release(); shRes.release(); active.release(); pathDepth.release();
+		litL.release(); litS.release(); counters.release(); out.release();
 	}
 };
 
@@ -259,25 +259,31 @@ void mark(mirt_scene* s, hipStream_t st, int kind) {
 	s->nLaunches++;
 }
 
+// One frame.  T(d) traces every ray of depth d in one launch: the reflection rays of that depth together with the shadow
+// queries of the hits of depth d-1; shade(d) evaluates the lights for the hits of depth d once those queries are answered:
+//     T(0) | T(1) shade(0) | T(2) shade(1) | ... | T(last+1: shadow queries only) shade(last) | resolve
 template <int MODE, bool OVF>
 void launch_frame(mirt_scene* s, const DFrame& F, uint8_t* out, hipStream_t st) {
 	const int grid = s->numCUs * GRID_BLOCKS_PER_CU;
+	const int sgrid = s->numCUs * 8;
 	int launch = 0;
 	s->nLaunches = 0;
 	mark(s, st, -1);
-	hipLaunchKernelGGL((k_primary<MODE, OVF>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, out, launch++);
+	hipLaunchKernelGGL((k_trace<MODE, OVF, true>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, out, 0, launch++, 0);
 	mark(s, st, MIRT_K_PRIMARY);
 	if (F.debug != D_PRIMARY_MAP) {
 		const int last = (F.features & F_REFLECTIONS) ? s->maxDepth : 0;
+		const bool shadowRays = (F.features & F_SHADOWS) && s->nLights > 0;
 		for (int depth = 0; depth <= last; ++depth) {
-			if (depth > 0) {
-				hipLaunchKernelGGL((k_trace<MODE, OVF>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, depth, launch++);
+			const int spawn = depth < last ? 1 : 0; // reflection rays exist while depth+1 <= maxDepth (main.cpp:177)
+			if (spawn || shadowRays) {
+				hipLaunchKernelGGL((k_trace<MODE, OVF, false>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, out, depth + 1, launch++, spawn);
 				mark(s, st, MIRT_K_TRACE);
 			}
-			hipLaunchKernelGGL((k_shade<MODE, OVF>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, depth, launch++);
+			hipLaunchKernelGGL(k_shade, dim3(sgrid), dim3(BLOCK), 0, st, s->ds, F, depth);
 			mark(s, st, MIRT_K_SHADE);
 		}
-		hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(BLOCK), 0, st, F, out);
+		hipLaunchKernelGGL(k_resolve, dim3(sgrid), dim3(BLOCK), 0, st, F, out);
 		mark(s, st, MIRT_K_RESOLVE);
 	}
 }
@@ -302,22 +308,23 @@ int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 	Workspace& w = s->ws;
 	const size_t n = (size_t)g.nSlots;
 	const size_t depths = (size_t)s->maxDepth + 1;
-	if ((e = w.rayO.ensure(2 * n * 16))) return e;
-	if ((e = w.rayD.ensure(2 * n * 16))) return e;
-	if ((e = w.hitO.ensure(n * 16))) return e;
-	if ((e = w.hitD.ensure(n * 16))) return e;
-	if ((e = w.hitN.ensure(n * 16))) return e;
-	if ((e = w.hit0.ensure(n * 4))) return e;
+	const size_t nl = s->nLights;
+	if (n * (nl + 1) >= 0xffffffffull) return fail(MIRT_E_INVALID, "too many rays per depth for one launch (%zu slots x %zu lights)", n, nl);
+	if ((e = w.hitO.ensure(2 * n * 16))) return e;
+	if ((e = w.hitD.ensure(2 * n * 16))) return e;
+	if ((e = w.hitN.ensure(2 * n * 16))) return e;
+	if ((e = w.shRes.ensure((nl ? n * nl : 1) * 8))) return e;
 	if ((e = w.litL.ensure(depths * n * 16))) return e;
 	if ((e = w.litS.ensure(depths * n * 16))) return e;
-	if ((e = w.depthCnt.ensure(n))) return e;
+	if ((e = w.pathDepth.ensure(n))) return e;
+	if ((e = w.active.ensure(2 * n * 4))) return e;
 	if ((e = w.counters.ensure(CTR_COUNT * 4))) return e;
 	DFrame F;
-	F.rayO = (float4*)w.rayO.p; F.rayD = (float4*)w.rayD.p;
 	F.hitO = (float4*)w.hitO.p; F.hitD = (float4*)w.hitD.p; F.hitN = (float4*)w.hitN.p;
-	F.hit0 = (uint32_t*)w.hit0.p;
+	F.shRes = (uint2*)w.shRes.p;
 	F.litL = (float4*)w.litL.p; F.litS = (float4*)w.litS.p;
-	F.depthCnt = (uint8_t*)w.depthCnt.p;
+	F.pathDepth = (uint8_t*)w.pathDepth.p;
+	F.active = (uint32_t*)w.active.p;
 	F.counters = (uint32_t*)w.counters.p;
 	F.nSlots = (uint32_t)g.nSlots;
 	F.width = p->width; F.height = p->height;
@@ -355,10 +362,13 @@ int read_stats(mirt_scene* s, hipStream_t st, mirt_stats* out) {
 	HIPCHK(hipMemcpy(c, s->ws.counters.p, sizeof c, hipMemcpyDeviceToHost));
 	uint64_t hits = 0, refl = 0;
 	for (int d = 0; d <= s->maxDepth; ++d) hits += c[CTR_NHITS(d)];
-	for (int d = 1; d <= s->maxDepth; ++d) refl += c[CTR_NRAYS(d)];
+	// a reflection ray is traced for every hit at depth d < maxDepth when REFLECTIONS is on (main.cpp:177,189-190)
+	if (s->lastFeatures & MIRT_F_REFLECTIONS) for (int d = 0; d < s->maxDepth; ++d) refl += c[CTR_NHITS(d)];
 	out->primary_hits = c[CTR_NHITS(0)];
 	out->shadow_rays = hits * s->nLights; // main.cpp:208-223: one query per light per hit, whatever the feature bits
-	out->shadow_rays_traced = (s->lastFeatures & MIRT_F_SHADOWS) ? out->shadow_rays : 0;
+	uint64_t traced = 0;
+	for (int d = 0; d <= s->maxDepth; ++d) traced += c[CTR_NSHADOW(d)];
+	out->shadow_rays_traced = traced;
 	out->reflection_rays = out->reflection_rays_traced = refl;
 	float ms = 0.0f;
 	HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));

@@ -79,17 +79,16 @@ struct DScene {
 	DCamera cam;
 };
 
-// One frame's working set.  All queues are sized for every pixel slot of the launch.
+// One frame's working set.  Every array is indexed by pixel slot: a pixel has exactly one path.
 struct DFrame {
-	float4* rayO;      // ray queue: { o.xyz, slot }   (two halves, ping-pong by depth parity)
-	float4* rayD;      //            { d.xyz, 0 }
-	float4* hitO;      // hit queue: { o.xyz, slot }
-	float4* hitD;      //            { d.xyz, dist }
+	float4* hitO;      // hit records, two sets of nSlots (depth parity): { ray o.xyz, 0 }
+	float4* hitD;      //            { ray d.xyz, dist }
 	float4* hitN;      //            { n.xyz, prim ref }
-	uint32_t* hit0;    // slots whose primary ray hit something (input of the resolve pass)
+	uint2* shRes;      // [slot * nLights + light] answer of a shadow query: { occluder ref or REF_NONE, dist bits }
+	uint32_t* active;  // two lists of up to nSlots slots (depth parity): the slots whose path hit something at that depth
+	uint8_t* pathDepth; // [slot] number of hits the pixel's path has had so far (0 = primary ray missed)
 	float4* litL;      // [depth][slot] light sum of the hit at that depth
 	float4* litS;      // [depth][slot] mat.specular of that hit (weight of the next bounce)
-	uint8_t* depthCnt; // [slot] number of depths with a hit
 	uint32_t* counters; // see CTR_* below
 	uint32_t nSlots;    // pixel slots in this launch (tiles x tile area)
 	uint32_t width, height;
@@ -98,8 +97,8 @@ struct DFrame {
 	uint32_t packedTiles; // output layout: 0 = full image, 1 = packed tile buffer
 };
 
-// counters[]: work cursors and queue lengths, zeroed at the start of every frame
+// counters[]: work cursors and statistics, zeroed at the start of every frame
 #define CTR_CURSOR(launch) (launch)              // 0..63  one dynamic-chunk cursor per kernel launch of the frame
 #define CTR_NHITS(depth) (64 + (depth))          // hits found at this depth
-#define CTR_NRAYS(depth) (64 + 32 + (depth))     // rays queued for this depth (depth >= 1)
-#define CTR_COUNT 128
+#define CTR_NSHADOW(depth) (64 + 64 + (depth))   // shadow queries traced for the hits of this depth
+#define CTR_COUNT 192

@@ -355,21 +355,37 @@ struct LdsStack {
 	}
 };
 
-template <int MODE, bool ANY, bool OVF>
-__device__ __forceinline__ bool traverse_bvh(const DScene& S, const RayCtx& r, float limit, Hit& best, LdsStack<OVF>& stk) {
-	best.dist = __builtin_inff();
-	best.ref = REF_NONE;
-	best.pos = 0xffffffffu;
-	float tcull = ANY ? (limit * r.invLen * 1.0001f + 1e-5f) : __builtin_inff();
-	uint32_t cur = S.bvhRoot;
-	{
+// One ray's walk of the primitive hierarchy, written as a resumable object so that a wave can hand a lane a new ray
+// as soon as its old one is finished (k_trace).  limit >= 0: shadow query "is there a hit with dist < limit"
+// (main.cpp:223-224); limit < 0: nearest hit under the reference's tie rules.
+// Children are visited nearer-first and a subtree is skipped when its entry parameter exceeds `tcull`, a bound kept
+// slightly beyond the best distance so far, so every candidate at a distance <= best is still visited.
+template <int MODE, bool OVF>
+struct Walker {
+	RayCtx r;
+	float limit;
+	float tcull;
+	Hit best;
+	uint32_t cur;
+	int sp;
+
+	__device__ __forceinline__ bool start(const DScene& S, f3 o, f3 d, float lim) {
+		r = make_ray(o, d);
+		limit = lim;
+		best.dist = __builtin_inff();
+		best.ref = REF_NONE;
+		best.pos = 0xffffffffu;
+		tcull = lim >= 0.0f ? (lim * r.invLen * 1.0001f + 1e-5f) : __builtin_inff();
+		sp = 0;
+		cur = S.bvhRoot;
 		float tn;
 		const float4 lo = make_float4(S.bvhMin[0], S.bvhMin[1], S.bvhMin[2], 0.0f), hi = make_float4(S.bvhMax[0], S.bvhMax[1], S.bvhMax[2], 0.0f);
-		if (cur == BVH_DONE || !box_filter(r, lo, hi, tcull, tn)) return false;
+		if (cur == BVH_DONE || !box_filter(r, lo, hi, tcull, tn)) cur = BVH_DONE;
+		return cur != BVH_DONE;
 	}
-	int sp = 0;
-	for (;;) {
-		// descend through interior nodes
+
+	// One round: descend to the next leaf, test its primitives, pop.  Returns false when the walk is over.
+	__device__ __forceinline__ bool advance(const DScene& S, LdsStack<OVF>& stk) {
 		while (!(cur & BVH_LEAF)) {
 			const float4* nd = S.bvh + (size_t)cur * 4;
 			const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
@@ -388,11 +404,12 @@ __device__ __forceinline__ bool traverse_bvh(const DScene& S, const RayCtx& r, f
 			else if (sp > 0) cur = stk.pop(--sp);
 			else cur = BVH_DONE;
 		}
-		if (cur == BVH_DONE) break;
+		if (cur == BVH_DONE) return false;
 		// leaf: 1..8 consecutive records of one kind
 		const uint32_t first = cur & BVH_FIRST_MASK;
 		const uint32_t cnt = ((cur >> BVH_COUNT_SHIFT) & 7u) + 1u;
 		const bool sph = (cur & BVH_SPHERES) != 0;
+		const bool any = limit >= 0.0f;
 		for (uint32_t k = 0; k < cnt; ++k) {
 			const uint32_t idx = first + k;
 			float dist;
@@ -405,41 +422,48 @@ __device__ __forceinline__ bool traverse_bvh(const DScene& S, const RayCtx& r, f
 			}
 			if (!(dist >= 0.0f) || isinf(dist)) continue;
 			const uint32_t ref = sph ? (PRIM_SPHERE | idx) : idx;
-			if (ANY) {
-				if (dist < limit) {
-					uint32_t pos = 0;
-					if (MODE == MODE_EXACT) {
-						const uint4 info = sph ? S.sphInfo[idx] : S.triInfo[idx];
-						pos = membership(S, r, info.z, info.w);
-					}
-					if (pos != REF_NONE) { best.dist = dist; best.ref = ref; best.pos = pos; return true; }
-				}
+			const bool cand = any ? (dist < limit) : (dist < best.dist || (dist == best.dist && ref != best.ref));
+			if (!cand) continue;
+			uint32_t pos = 0;
+			if (MODE == MODE_EXACT) {
+				const uint4 info = sph ? S.sphInfo[idx] : S.triInfo[idx];
+				pos = membership(S, r, info.z, info.w);
 			}
-			else if (dist < best.dist || (dist == best.dist && ref != best.ref)) {
-				uint32_t pos = 0;
-				if (MODE == MODE_EXACT) {
-					const uint4 info = sph ? S.sphInfo[idx] : S.triInfo[idx];
-					pos = membership(S, r, info.z, info.w);
-				}
-				// Partition.h:33 (first in a leaf wins), Partition.cpp:47 (left subtree wins) == lower visiting rank wins
-				if (pos != REF_NONE && (dist < best.dist || pos < best.pos)) {
-					best.dist = dist;
-					best.ref = ref;
-					best.pos = pos;
-					tcull = dist * r.invLen * 1.0001f + 1e-5f;
-				}
+			if (pos == REF_NONE) continue; // the reference's tree never reaches this primitive along this ray
+			if (any) {
+				best.dist = dist;
+				best.ref = ref;
+				best.pos = pos;
+				cur = BVH_DONE;
+				return false;
+			}
+			// Partition.h:33 (first in a leaf wins), Partition.cpp:47 (left subtree wins) == lower visiting rank wins
+			if (dist < best.dist || pos < best.pos) {
+				best.dist = dist;
+				best.ref = ref;
+				best.pos = pos;
+				tcull = dist * r.invLen * 1.0001f + 1e-5f;
 			}
 		}
-		if (sp == 0) break;
+		if (sp == 0) { cur = BVH_DONE; return false; }
 		cur = stk.pop(--sp);
+		return true;
 	}
-	return best.ref != REF_NONE;
-}
+};
 
-template <int MODE, bool ANY, bool OVF>
-__device__ __forceinline__ bool trace_ray(const DScene& S, const RayCtx& r, float limit, Hit& best, LdsStack<OVF>& stk) {
-	if (MODE == MODE_REFWALK) return traverse_ref<ANY>(S, r, limit, best);
-	return traverse_bvh<MODE, ANY, OVF>(S, r, limit, best, stk);
+// whole walk at once (test hooks and MODE_REFWALK dispatch)
+template <int MODE, bool OVF>
+__device__ __forceinline__ void trace_whole(const DScene& S, f3 o, f3 d, float limit, Hit& best, LdsStack<OVF>& stk) {
+	if (MODE == MODE_REFWALK) {
+		const RayCtx r = make_ray(o, d);
+		if (limit >= 0.0f) traverse_ref<true>(S, r, limit, best);
+		else traverse_ref<false>(S, r, limit, best);
+		return;
+	}
+	Walker<MODE == MODE_REFWALK ? MODE_EXACT : MODE, OVF> w;
+	bool alive = w.start(S, o, d, limit);
+	while (alive) alive = w.advance(S, stk);
+	best = w.best;
 }
 
 // Intersection::intersectNormal of the winning primitive (normalised by the Intersection ctor, SceneObjects.hpp:39)
@@ -485,217 +509,265 @@ __device__ __forceinline__ size_t out_offset(const DFrame& F, uint32_t slot, uin
 	return ((size_t)py * F.width + px) * 3; // main.cpp:154-156
 }
 
-// wave-aggregated queue append: one atomic per wave
-__device__ __forceinline__ uint32_t queue_push(uint32_t* counter, bool want) {
-	const unsigned long long m = __ballot(want);
-	if (m == 0ull) return 0;
+// append this wave's n collected slots (LDS) to a global list: one atomic, coalesced stores
+__device__ __forceinline__ void flush_list(const uint32_t* lds, uint32_t n, uint32_t* list, uint32_t* counter) {
 	const int lane = threadIdx.x & 63;
-	const int leader = __ffsll((long long)m) - 1;
 	uint32_t base = 0;
-	if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-	base = __shfl(base, leader);
-	return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+	if (lane == 0) base = atomicAdd(counter, n);
+	base = __builtin_amdgcn_readfirstlane(base);
+	for (uint32_t i = lane; i < n; i += 64) list[base + i] = lds[i];
 }
 
-// Work distribution: a wave owns GRAB consecutive 64-item chunks at a time.  Its first batch is static (wave index),
-// later batches come from one atomic cursor per launch -- one atomic per GRAB*64 items keeps the cursor word far
-// below the ~88 atomics/us a single address sustains.
-template <int GRAB>
-struct Dealer {
+// ---- wave-local supply of work items -------------------------------------------------------------------------------------
+// Items 0..n-1 are handed out in blocks: a wave's first block is static (its index), later blocks come from one atomic
+// cursor per launch.  The block size adapts to the launch: 256 items when there is plenty of work (one atomic per 256
+// items keeps the cursor word far below the ~88 atomics/us one address sustains), down to 64 when there is little, so
+// that a small launch spreads over many waves instead of queueing on a few.
+struct Supply {
 	uint32_t* cursor;
-	uint32_t cb, ce, stride0;
-	__device__ __forceinline__ Dealer(uint32_t* c) : cursor(c) {
+	uint32_t n, cb, ce, stride0, blk;
+	__device__ __forceinline__ Supply(uint32_t* c, uint32_t count) : cursor(c), n(count) {
+		const uint32_t nWaves = gridDim.x * (BLOCK / WAVE);
 		const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
-		stride0 = gridDim.x * (BLOCK / WAVE) * (WAVE * GRAB);
-		cb = wave * (WAVE * GRAB);
-		ce = cb + WAVE * GRAB;
+		const uint32_t per = count / (2u * nWaves);
+		blk = per >= 256u ? 256u : (per >= 128u ? 128u : 64u);
+		stride0 = nWaves * blk;
+		cb = wave * blk;
+		ce = cb + blk;
 	}
-	// base of the next 64-item chunk (>= n means: no more work)
-	__device__ __forceinline__ uint32_t next() {
-		if (cb >= ce) {
+	__device__ __forceinline__ bool exhausted() const { return cb >= n; }
+	// up to `want` consecutive items: returns how many, first index in base
+	__device__ __forceinline__ uint32_t take(uint32_t want, uint32_t& base) {
+		if (cb >= ce && cb < n) {
 			uint32_t c = 0;
-			if ((threadIdx.x & 63) == 0) c = atomicAdd(cursor, (uint32_t)(WAVE * GRAB));
+			if ((threadIdx.x & 63) == 0) c = atomicAdd(cursor, blk);
 			cb = __builtin_amdgcn_readfirstlane(c) + stride0;
-			ce = cb + WAVE * GRAB;
+			ce = cb + blk;
 		}
-		const uint32_t b = cb;
-		cb += WAVE;
-		return b;
+		if (cb >= n) { cb = n; ce = n; return 0; }
+		const uint32_t end = ce < n ? ce : n;
+		const uint32_t got = want < end - cb ? want : end - cb;
+		base = cb;
+		cb += got;
+		return got;
 	}
 };
 
-// ---- depth 0: generate + trace primary rays -----------------------------------------------------------------------
-template <int MODE, bool OVF>
-__global__ __launch_bounds__(BLOCK) void k_primary(DScene S, DFrame F, uint8_t* __restrict__ out, int launch) {
-	__shared__ uint32_t s_stack[MODE == MODE_REFWALK ? 1 : STACK_LDS * BLOCK];
-	LdsStack<OVF> stk;
-	stk.lds = s_stack + (MODE == MODE_REFWALK ? 0 : threadIdx.x);
-	stk.ovf = OVF ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
-	stk.ovfStride = S.ovfStride;
-	Dealer<4> deal(F.counters + CTR_CURSOR(launch));
-	for (;;) {
-		const uint32_t base = deal.next();
-		if (base >= F.nSlots) return;
-		const uint32_t slot = base + (threadIdx.x & 63);
-		uint32_t px, py, inTile;
-		const bool live = slot_to_pixel(F, slot, px, py, inTile);
-		Hit h;
-		h.ref = REF_NONE;
-		f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
-		RayCtx r;
-		if (live) {
-			primary_ray(S, px, py, F.width, F.height, o, d);
-			r = make_ray(o, d);
-			trace_ray<MODE, false, OVF>(S, r, 0.0f, h, stk);
-		}
-		const bool hit = live && h.ref != REF_NONE;
-		if (live && (!hit || F.debug == D_PRIMARY_MAP)) {
-			// background is black (main.cpp:124,180); PRIMARY_INTERSECTION_MAP paints hits pure red (main.cpp:183-185)
-			const size_t k = out_offset(F, slot, px, py, inTile);
-			out[k] = 0;
-			out[k + 1] = 0;
-			out[k + 2] = hit ? 255 : 0;
-		}
-		const bool enq = hit && F.debug != D_PRIMARY_MAP;
-		const uint32_t q = queue_push(F.counters + CTR_NHITS(0), enq);
-		if (enq) {
-			const f3 n = hit_normal(S, r, h.ref);
-			F.hitO[q] = make_float4(o.x, o.y, o.z, __uint_as_float(slot));
-			F.hitD[q] = make_float4(d.x, d.y, d.z, h.dist);
-			F.hitN[q] = make_float4(n.x, n.y, n.z, __uint_as_float(h.ref));
-			F.hit0[q] = slot;
-		}
-	}
-}
+#ifndef MIRT_REFILL_MIN
+#define MIRT_REFILL_MIN 20
+#endif
 
-// ---- depth >= 1: trace queued reflection rays ---------------------------------------------------------------------
-template <int MODE, bool OVF>
-__global__ __launch_bounds__(BLOCK) void k_trace(DScene S, DFrame F, int depth, int launch) {
-	__shared__ uint32_t s_stack[MODE == MODE_REFWALK ? 1 : STACK_LDS * BLOCK];
+// ---- the tracing kernel: every ray of one depth in one launch ---------------------------------------------------------------
+// Per-path data (hit records, shadow answers, light sums) is indexed by pixel slot: a pixel has one path (main.cpp:176-201
+// recurses once per hit), so records are never moved.  What a depth works on is the list F.active[parity] of the slots
+// whose path hit something at the previous depth; a wave collects the slots it finds hits for in LDS and appends them to
+// the next list 192+ at a time (one atomic per flush).
+//
+// PRIMARY (depth 0): items are pixel slots; the ray comes from the camera (main.cpp:152).
+// depth d >= 1: with n = hits of depth d-1, items [0, n*nLights) are the shadow queries of those hits -- ray
+//   (P, normalize(L)), "is anything closer than |L|" (main.cpp:222-224) -- and items from n*nLights on are their
+//   reflection rays (P, R) (main.cpp:188-190); both are derived here from the hit record of depth d-1, so no ray is ever
+//   stored.  Results: a hit record for depth d (nearest-hit rays), or the occluder in F.shRes (shadow queries; the
+//   SHADOW_MAP view asks for the nearest occluder, main.cpp:250-252).
+// A lane whose ray is finished parks its result; once MIRT_REFILL_MIN lanes are parked they write their results
+// together and receive new rays, so the wave does not idle behind its longest ray.
+template <int MODE, bool OVF, bool PRIMARY>
+__global__ __launch_bounds__(BLOCK) void k_trace(DScene S, DFrame F, uint8_t* __restrict__ out, int depth, int launch, int spawn) {
+	__shared__ uint32_t s_stack[STACK_LDS * BLOCK];
+	__shared__ uint32_t s_list[BLOCK / WAVE][256];
 	LdsStack<OVF> stk;
-	stk.lds = s_stack + (MODE == MODE_REFWALK ? 0 : threadIdx.x);
+	stk.lds = s_stack + threadIdx.x;
 	stk.ovf = OVF ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
 	stk.ovfStride = S.ovfStride;
-	const uint32_t n = F.counters[CTR_NRAYS(depth)];
-	const size_t half = (size_t)(depth & 1) * F.nSlots;
-	Dealer<1> deal(F.counters + CTR_CURSOR(launch));
+	const int lane = threadIdx.x & 63;
+	const unsigned long long ltMask = (1ull << lane) - 1ull;
+	// hit records: read those of depth-1, write those of depth
+	const size_t rd = (size_t)((depth + 1) & 1) * F.nSlots, wr = (size_t)(depth & 1) * F.nSlots;
+	const uint32_t nPrev = PRIMARY ? 0u : F.counters[CTR_NHITS(depth - 1)];
+	const uint32_t nShadowItems = (F.features & F_SHADOWS) ? nPrev * S.nLights : 0u;
+	const uint32_t nTotal = PRIMARY ? F.nSlots : nShadowItems + (spawn ? nPrev : 0u);
+	const uint32_t* prevList = F.active + rd;
+	uint32_t* nextList = F.active + wr;
+	uint32_t* myList = s_list[threadIdx.x >> 6];
+	uint32_t nbuf = 0;
+	Supply sup(F.counters + CTR_CURSOR(launch), nTotal);
+	Walker<MODE, OVF> w;
+	bool alive = false, parked = false;
+	uint32_t tag = 0;
+	uint32_t nShadowTraced = 0;
 	for (;;) {
-		const uint32_t base = deal.next();
-		if (base >= n) return;
-		const uint32_t i = base + (threadIdx.x & 63);
-		const bool live = i < n;
-		Hit h;
-		h.ref = REF_NONE;
-		float4 ro = make_float4(0, 0, 0, 0), rd = make_float4(0, 0, 1, 0);
-		RayCtx r;
-		if (live) {
-			ro = F.rayO[half + i];
-			rd = F.rayD[half + i];
-			r = make_ray(F3(ro), F3(rd));
-			trace_ray<MODE, false, OVF>(S, r, 0.0f, h, stk);
-		}
-		const bool hit = live && h.ref != REF_NONE;
-		const uint32_t q = queue_push(F.counters + CTR_NHITS(depth), hit);
-		if (hit) {
-			const f3 nn = hit_normal(S, r, h.ref);
-			F.hitO[q] = ro;
-			F.hitD[q] = make_float4(rd.x, rd.y, rd.z, h.dist);
-			F.hitN[q] = make_float4(nn.x, nn.y, nn.z, __uint_as_float(h.ref));
-		}
-	}
-}
-
-// ---- shade the hits of one depth: lights, shadow rays, spawn the reflection ray -------------------------------------
-template <int MODE, bool OVF>
-__global__ __launch_bounds__(BLOCK) void k_shade(DScene S, DFrame F, int depth, int launch) {
-	__shared__ uint32_t s_stack[MODE == MODE_REFWALK ? 1 : STACK_LDS * BLOCK];
-	LdsStack<OVF> stk;
-	stk.lds = s_stack + (MODE == MODE_REFWALK ? 0 : threadIdx.x);
-	stk.ovf = OVF ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
-	stk.ovfStride = S.ovfStride;
-	const uint32_t n = F.counters[CTR_NHITS(depth)];
-	const size_t nextHalf = (size_t)((depth + 1) & 1) * F.nSlots;
-	const bool spawn = (F.features & F_REFLECTIONS) && (depth + 1 <= S.maxDepth) && F.debug != D_PRIMARY_MAP; // main.cpp:177,189
-	Dealer<1> deal(F.counters + CTR_CURSOR(launch));
-	for (;;) {
-		const uint32_t base = deal.next();
-		if (base >= n) return;
-		const uint32_t i = base + (threadIdx.x & 63);
-		const bool live = i < n;
-		f3 P = F3(0, 0, 0), R = F3(0, 0, 1);
-		uint32_t slot = 0;
-		if (live) {
-			const float4 ho = F.hitO[i], hd = F.hitD[i], hn = F.hitN[i];
-			const f3 o = F3(ho), d = F3(hd), N = F3(hn);
-			slot = __float_as_uint(ho.w);
-			const float dist = hd.w;
-			const uint32_t ref = __float_as_uint(hn.w);
-			const float4* mat = S.materials + (size_t)info_of(S, ref).y * 4;
-			const float4 mDiff = mat[0], mSpec = mat[1], mEmis = mat[2], mAmb = mat[3];
-			const float shininess = mDiff.w;
-			P = o + normalize3(d) * dist;                                   // Camera.cpp:26-28
-			f3 sum = F3(mAmb) + F3(mEmis);                                  // main.cpp:204
-			for (uint32_t li = 0; li < S.nLights; ++li) {                   // :208
-				const float4 ll = S.lights[li * 2], lc = S.lights[li * 2 + 1];
-				f3 L;
-				float atten;
-				if (ll.w > 0.0f) {                                          // :213
-					L = F3(ll) - P;                                         // :214
-					const float dl = length3(L);                            // :215
-					atten = 1.0f / (S.atten[0] + S.atten[1] * dl + S.atten[2] * (dl * dl)); // :266-268
+		const unsigned long long idle = __ballot(!alive);
+		const int nIdle = __popcll(idle);
+		if (nIdle >= MIRT_REFILL_MIN || sup.exhausted()) {
+			// (1) parked lanes write their results
+			bool newHit = false;
+			if (parked) {
+				const bool hit = w.best.ref != REF_NONE;
+				if (w.limit == -1.0f) {
+					if (PRIMARY) {
+						if (!hit || F.debug == D_PRIMARY_MAP) {
+							// background is black (main.cpp:124,180); PRIMARY_INTERSECTION_MAP paints hits pure red (main.cpp:183-185)
+							uint32_t px, py, inTile;
+							slot_to_pixel(F, tag, px, py, inTile);
+							const size_t k = out_offset(F, tag, px, py, inTile);
+							out[k] = 0;
+							out[k + 1] = 0;
+							out[k + 2] = hit ? 255 : 0;
+						}
+						F.pathDepth[tag] = (hit && F.debug != D_PRIMARY_MAP) ? 1 : 0;
+					}
+					if (hit) {
+						newHit = true;
+						const f3 n = hit_normal(S, w.r, w.best.ref);
+						F.hitO[wr + tag] = make_float4(w.r.o.x, w.r.o.y, w.r.o.z, 0.0f);
+						F.hitD[wr + tag] = make_float4(w.r.d.x, w.r.d.y, w.r.d.z, w.best.dist);
+						F.hitN[wr + tag] = make_float4(n.x, n.y, n.z, __uint_as_float(w.best.ref));
+						if (!PRIMARY) F.pathDepth[tag] = (uint8_t)(depth + 1);
+					}
 				}
 				else {
-					L = F3(ll);                                             // :219
-					atten = 1.0f;
+					F.shRes[tag] = make_uint2(w.best.ref, __float_as_uint(w.best.dist));
 				}
-				const f3 Ln = normalize3(L);                                // :222
-				const float lenL = length3(L);                              // :224
-				bool lit = true;
-				Hit occ;
-				occ.ref = REF_NONE;
-				if (F.features & F_SHADOWS) {
-					const RayCtx sr = make_ray(P, Ln);
-					if (F.debug == D_SHADOW_MAP) {
-						trace_ray<MODE, false, OVF>(S, sr, 0.0f, occ, stk);
-						lit = (occ.ref == REF_NONE) || (occ.dist >= lenL);
-					}
-					else {
-						lit = !trace_ray<MODE, true, OVF>(S, sr, lenL, occ, stk);
-					}
-				}
-				if (lit) {
-					const float kd = fmaxf(dot3(normalize3(N), normalize3(L)), 0.0f); // :225, :258-260
-					const f3 eye = o - P;                                              // :226
-					const f3 H = normalize3(Ln + normalize3(eye));                     // :227
-					// :262-264 powf; evaluated in double and rounded once, which reproduces a correctly rounded powf
-					const float ks = (float)pow((double)fmaxf(dot3(H, N), 0.0f), (double)shininess);
-					if (F.debug == D_DIFFUSE_INTENSITY) sum = sum + F3(kd, kd, kd);
-					else if (F.debug == D_SPECULAR_INTENSITY) sum = sum + F3(ks, ks, ks);
-					else if (F.debug == D_NORMAL_MAP) sum = sum + N;
-					else if (F.debug == D_LIGHT_DIR_MAP) sum = sum + H;
-					else {
-						if (F.features & F_DIFFUSE) sum = sum + ((F3(mDiff) * atten) * kd) * F3(lc);  // :243
-						if (F.features & F_SPECULAR) sum = sum + ((F3(mSpec) * atten) * ks) * F3(lc); // :246
-					}
-				}
-				else if (F.debug == D_SHADOW_MAP) {
-					const float4* om = S.materials + (size_t)info_of(S, occ.ref).y * 4;
-					sum = sum + F3(om[0]);                                  // :250-252
+				parked = false;
+			}
+			// slots with a new hit go to this wave's LDS list, which is appended to the next depth's list in large pieces
+			{
+				const unsigned long long hm = __ballot(newHit);
+				if (hm) {
+					if (newHit) myList[nbuf + (uint32_t)__popcll(hm & ltMask)] = tag;
+					nbuf += (uint32_t)__popcll(hm);
+					if (nbuf >= 192u) { flush_list(myList, nbuf, nextList, F.counters + CTR_NHITS(depth)); nbuf = 0; }
 				}
 			}
-			const size_t k = (size_t)depth * F.nSlots + slot;
-			F.litL[k] = make_float4(sum.x, sum.y, sum.z, 0.0f);
-			F.litS[k] = make_float4(mSpec.x, mSpec.y, mSpec.z, 0.0f);
-			F.depthCnt[slot] = (uint8_t)(depth + 1);
-			R = normalize3(d - N * (2.0f * dot3(d, N)));                    // :188
+			// (2) idle lanes take new items
+			uint32_t base = 0;
+			const uint32_t got = sup.take((uint32_t)nIdle, base);
+			const uint32_t rank = (uint32_t)__popcll(idle & ltMask);
+			if (!alive && rank < got) {
+				const uint32_t item = base + rank;
+				f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
+				float lim = -1.0f;
+				bool live;
+				if (PRIMARY) {
+					uint32_t px, py, inTile;
+					live = slot_to_pixel(F, item, px, py, inTile);
+					tag = item;
+					if (!live) F.pathDepth[item] = 0; // padding pixel of an edge tile: no path
+					primary_ray(S, px, py, F.width, F.height, o, d);
+				}
+				else {
+					const bool shadow = item < nShadowItems;
+					const uint32_t h = shadow ? item / S.nLights : item - nShadowItems;
+					const uint32_t slot = prevList[h];
+					live = true;
+					if (live) {
+						const float4 ho = F.hitO[rd + slot], hd = F.hitD[rd + slot];
+						const f3 po = F3(ho), pd = F3(hd);
+						o = po + normalize3(pd) * hd.w;                               // P, Camera.cpp:26-28
+						if (shadow) {
+							const uint32_t li = item - h * S.nLights;
+							const float4 ll = S.lights[li * 2];
+							const f3 L = ll.w > 0.0f ? F3(ll) - o : F3(ll);           // main.cpp:213-219
+							d = normalize3(L);                                        // :222
+							lim = F.debug == D_SHADOW_MAP ? -2.0f : length3(L);       // :224
+							tag = slot * S.nLights + li;
+							++nShadowTraced;
+						}
+						else {
+							const f3 N = F3(F.hitN[rd + slot]);
+							d = normalize3(pd - N * (2.0f * dot3(pd, N)));            // main.cpp:188
+							tag = slot;
+						}
+					}
+				}
+				if (live) {
+					if (MODE == MODE_REFWALK) {
+						// the reference's own tree, walked in one go (fallback / cross-check mode)
+						w.r = make_ray(o, d);
+						w.limit = lim;
+						trace_whole<MODE_REFWALK, OVF>(S, o, d, lim, w.best, stk);
+						parked = true;
+					}
+					else {
+						alive = w.start(S, o, d, lim);
+						parked = !alive; // missed the whole scene: result is "no hit"
+					}
+				}
+			}
+			if (got == 0 && __ballot(alive || parked) == 0ull) break;
 		}
-		if (spawn) {
-			const uint32_t q = queue_push(F.counters + CTR_NRAYS(depth + 1), live);
-			if (live) {
-				F.rayO[nextHalf + q] = make_float4(P.x, P.y, P.z, __uint_as_float(slot));
-				F.rayD[nextHalf + q] = make_float4(R.x, R.y, R.z, 0.0f);
+		if (MODE != MODE_REFWALK && alive) {
+			alive = w.advance(S, stk);
+			parked = !alive;
+		}
+	}
+	if (nbuf) flush_list(myList, nbuf, nextList, F.counters + CTR_NHITS(depth));
+	// statistics: one atomic per wave
+	for (int off = 32; off > 0; off >>= 1) nShadowTraced += __shfl_down(nShadowTraced, off);
+	if (lane == 0 && nShadowTraced) atomicAdd(F.counters + CTR_NSHADOW(depth - 1), nShadowTraced);
+}
+
+// ---- once the shadow queries are answered: calculateLightingColor (main.cpp:203-256) for every hit of one depth ----------------
+__global__ __launch_bounds__(BLOCK) void k_shade(DScene S, DFrame F, int depth) {
+	const size_t rd = (size_t)(depth & 1) * F.nSlots;
+	const bool shadows = (F.features & F_SHADOWS) != 0;
+	const uint32_t n = F.counters[CTR_NHITS(depth)];
+	const uint32_t* list = F.active + rd;
+	for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+		const uint32_t slot = list[i];
+		const float4 ho = F.hitO[rd + slot], hd = F.hitD[rd + slot], hn = F.hitN[rd + slot];
+		const f3 o = F3(ho), d = F3(hd), N = F3(hn);
+		const uint32_t ref = __float_as_uint(hn.w);
+		const float4* mat = S.materials + (size_t)info_of(S, ref).y * 4;
+		const float4 mDiff = mat[0], mSpec = mat[1], mEmis = mat[2], mAmb = mat[3];
+		const float shininess = mDiff.w;
+		const f3 P = o + normalize3(d) * hd.w;                               // Camera.cpp:26-28
+		f3 sum = F3(mAmb) + F3(mEmis);                                      // main.cpp:204
+		for (uint32_t li = 0; li < S.nLights; ++li) {                       // :208
+			const float4 ll = S.lights[li * 2], lc = S.lights[li * 2 + 1];
+			f3 L;
+			float atten;
+			if (ll.w > 0.0f) {                                              // :213
+				L = F3(ll) - P;                                             // :214
+				const float dl = length3(L);                                // :215
+				atten = 1.0f / (S.atten[0] + S.atten[1] * dl + S.atten[2] * (dl * dl)); // :266-268
+			}
+			else {
+				L = F3(ll);                                                 // :219
+				atten = 1.0f;
+			}
+			const f3 Ln = normalize3(L);                                    // :222
+			bool lit = true;
+			uint32_t occRef = REF_NONE;
+			if (shadows) {
+				const uint2 res = F.shRes[(size_t)slot * S.nLights + li];
+				occRef = res.x;
+				// shadow query: any hit closer than |L| was reported; SHADOW_MAP view: nearest hit, compared here (main.cpp:224)
+				lit = (occRef == REF_NONE) || (F.debug == D_SHADOW_MAP && __uint_as_float(res.y) >= length3(L));
+			}
+			if (lit) {
+				const float kd = fmaxf(dot3(normalize3(N), normalize3(L)), 0.0f);   // :225, :258-260
+				const f3 eye = o - P;                                                // :226
+				const f3 H = normalize3(Ln + normalize3(eye));                       // :227
+				// :262-264 powf; evaluated in double and rounded once, which reproduces a correctly rounded powf
+				const float ks = (float)pow((double)fmaxf(dot3(H, N), 0.0f), (double)shininess);
+				if (F.debug == D_DIFFUSE_INTENSITY) sum = sum + F3(kd, kd, kd);
+				else if (F.debug == D_SPECULAR_INTENSITY) sum = sum + F3(ks, ks, ks);
+				else if (F.debug == D_NORMAL_MAP) sum = sum + N;
+				else if (F.debug == D_LIGHT_DIR_MAP) sum = sum + H;
+				else {
+					if (F.features & F_DIFFUSE) sum = sum + ((F3(mDiff) * atten) * kd) * F3(lc);  // :243
+					if (F.features & F_SPECULAR) sum = sum + ((F3(mSpec) * atten) * ks) * F3(lc); // :246
+				}
+			}
+			else if (F.debug == D_SHADOW_MAP) {
+				const float4* om = S.materials + (size_t)info_of(S, occRef).y * 4;
+				sum = sum + F3(om[0]);                                      // :250-252
 			}
 		}
+		const size_t k = (size_t)depth * F.nSlots + slot;
+		F.litL[k] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+		F.litS[k] = make_float4(mSpec.x, mSpec.y, mSpec.z, 0.0f);
 	}
 }
 
@@ -711,10 +783,11 @@ __device__ __forceinline__ uint8_t quantise(float c) { // Color.cpp:13-23
 
 // ---- fold the per-depth results back to front: C = L_k + S_k * C (main.cpp:190) and quantise ---------------------------
 __global__ __launch_bounds__(BLOCK) void k_resolve(DFrame F, uint8_t* __restrict__ out) {
-	const uint32_t n = F.counters[CTR_NHITS(0)];
-	for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
-		const uint32_t slot = F.hit0[i];
-		const int cnt = F.depthCnt[slot];
+	for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < F.nSlots; slot += gridDim.x * BLOCK) {
+		const int cnt = F.pathDepth[slot];
+		if (cnt == 0) continue; // the tracing kernel already wrote the background
+		uint32_t px, py, inTile;
+		if (!slot_to_pixel(F, slot, px, py, inTile)) continue;
 		f3 C = F3(0, 0, 0); // Color() past the last bounce (main.cpp:199) or the black background (main.cpp:124)
 		for (int k = cnt - 1; k >= 0; --k) {
 			const float4 L = F.litL[(size_t)k * F.nSlots + slot];
@@ -722,8 +795,6 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DFrame F, uint8_t* __restrict
 			if ((F.features & F_REFLECTIONS) || k > 0) C = F3(L) + F3(Sp) * C;
 			else C = F3(L); // main.cpp:193
 		}
-		uint32_t px, py, inTile;
-		slot_to_pixel(F, slot, px, py, inTile);
 		const size_t o = out_offset(F, slot, px, py, inTile);
 		out[o] = quantise(C.z);     // B  main.cpp:154
 		out[o + 1] = quantise(C.y); // G
@@ -744,7 +815,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_list(DScene S, uint64_t n, cons
 		const f3 o = F3(o3 + 3 * i), d = F3(d3 + 3 * i);
 		const RayCtx r = make_ray(o, d);
 		Hit h;
-		trace_ray<MODE, false, OVF>(S, r, 0.0f, h, stk);
+		trace_whole<MODE, OVF>(S, o, d, -1.0f, h, stk);
 		if (h.ref != REF_NONE) {
 			primId[i] = (int32_t)info_of(S, h.ref).x;
 			dist[i] = h.dist;
@@ -772,9 +843,8 @@ __global__ __launch_bounds__(BLOCK) void k_primary_ids(DScene S, uint32_t width,
 	for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
 		f3 o, d;
 		primary_ray(S, (uint32_t)(i % width), (uint32_t)(i / width), width, height, o, d);
-		const RayCtx r = make_ray(o, d);
 		Hit h;
-		trace_ray<MODE, false, OVF>(S, r, 0.0f, h, stk);
+		trace_whole<MODE, OVF>(S, o, d, -1.0f, h, stk);
 		primId[i] = h.ref != REF_NONE ? (int32_t)info_of(S, h.ref).x : -1;
 		dist[i] = h.ref != REF_NONE ? h.dist : __builtin_inff();
 	}
