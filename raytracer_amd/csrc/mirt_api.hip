@@ -76,7 +76,7 @@ struct mirt_scene {
 	int device = 0;
 	int numCUs = 256;
 	DScene ds;
-	DevBuf nodes, leafs, bvh, memb, tris, triInfo, spheres, sphInfo, materials, lights, ovf;
+	DevBuf nodes, leafs, bvh, memb, tris, triInfo, spheres, sphInfo, materials, lights, ovf, dbg;
 	bool nested = true;      // reference boxes nested: the primitive hierarchy may be used
 	uint32_t bvhDepth = 0;
 	bool deepBvh = false;    // hierarchy deeper than the LDS part of the traversal stack
@@ -661,6 +661,8 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	if (!e) e = upload(s->sphInfo, sphInfo.data(), sphInfo.size() * 4);
 	if (!e) e = upload(s->materials, mats.data(), mats.size() * 4);
 	if (!e) e = upload(s->lights, lights.data(), lights.size() * 4);
+	if (!e) { e = s->dbg.ensure(16 * 8); if (!e) (void)hipMemset(s->dbg.p, 0, 16 * 8); }
+	ds.dbg = (unsigned long long*)s->dbg.p;
 	ds.ovf = nullptr;
 	ds.ovfStride = (uint32_t)s->numCUs * GRID_BLOCKS_PER_CU * BLOCK;
 	s->deepBvh = bb.maxDepth + 1 > STACK_LDS;
@@ -695,7 +697,7 @@ void mirt_scene_destroy(mirt_scene* s) {
 	(void)hipSetDevice(s->device);
 	if (s->stream) (void)hipStreamSynchronize(s->stream);
 	s->nodes.release(); s->leafs.release(); s->bvh.release(); s->memb.release(); s->tris.release(); s->triInfo.release();
-	s->spheres.release(); s->sphInfo.release(); s->materials.release(); s->lights.release(); s->ovf.release();
+	s->spheres.release(); s->sphInfo.release(); s->materials.release(); s->lights.release(); s->ovf.release(); s->dbg.release();
 	s->ws.release();
 	if (s->ev0) (void)hipEventDestroy(s->ev0);
 	if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -731,7 +733,17 @@ int mirt_scene_query(mirt_scene* s, uint32_t what, uint64_t* v) {
 		     s->materials.bytes + s->lights.bytes + s->ovf.bytes;
 		break;
 	case MIRT_Q_TREE_WIDE_DEPTH: *v = s->wideDepth; break;
-	default: return fail(MIRT_E_INVALID, "unknown query %u", what);
+	default:
+		if (what >= 100 && what < 116) { // diagnostic event counters of MIRT_STATS builds (read and clear)
+			unsigned long long x = 0;
+			HIPCHK(hipSetDevice(s->device));
+			HIPCHK(hipDeviceSynchronize());
+			HIPCHK(hipMemcpy(&x, (char*)s->dbg.p + (what - 100) * 8, 8, hipMemcpyDeviceToHost));
+			HIPCHK(hipMemset((char*)s->dbg.p + (what - 100) * 8, 0, 8));
+			*v = x;
+			break;
+		}
+		return fail(MIRT_E_INVALID, "unknown query %u", what);
 	}
 	return MIRT_OK;
 }

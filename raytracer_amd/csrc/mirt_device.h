@@ -62,6 +62,7 @@ struct DScene {
 	const float4* memb;
 	// traversal stack overflow area (entries beyond the LDS part), [level][global thread]
 	uint32_t* ovf;
+	unsigned long long* dbg; // diagnostic event counters (MIRT_STATS builds)
 	uint32_t ovfStride;
 	uint32_t bvhRoot;
 	float bvhMin[3], bvhMax[3];

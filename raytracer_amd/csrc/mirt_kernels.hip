@@ -36,9 +36,15 @@
 #define MODE_FAST 1
 #define MODE_REFWALK 2
 
-#ifndef MIRT_BOX_FMA
-#define MIRT_BOX_FMA 0
+// diagnostic build only (-DMIRT_STATS=1): event counters, per wave-iteration and per lane
+#if MIRT_STATS
+#define STAT_LANE(S, k) atomicAdd((S).dbg + (k), 1ull)
+#define STAT_WAVE(S, k) do { if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd((S).dbg + (k), 1ull); } while (0)
+#else
+#define STAT_LANE(S, k)
+#define STAT_WAVE(S, k)
 #endif
+
 
 struct f3 {
 	float x, y, z;
@@ -71,11 +77,8 @@ struct RayCtx {
 	f3 o, d;
 	f3 e;      // direction with AABB.cpp:53-58's substitution: |d| < 1e-5 -> +1e-5
 	f3 ie;     // 1/d for the hierarchy's conservative box filter
-	float invLen; // 1/|d|, used only for conservative culling
-#if MIRT_BOX_FMA
 	f3 oie;    // o * ie
-	float ferr; // bound on the rounding error of the fused slab parameters
-#endif
+	float invLen; // 1/|d|, used only for conservative culling
 };
 
 __device__ __forceinline__ RayCtx make_ray(f3 o, f3 d) {
@@ -91,11 +94,7 @@ __device__ __forceinline__ RayCtx make_ray(f3 o, f3 d) {
 	const float sz = fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z;
 	r.ie = F3(1.0f / sx, 1.0f / sy, 1.0f / sz);
 	r.invLen = inv_sqrt(dot3(d, d));
-#if MIRT_BOX_FMA
 	r.oie = r.o * r.ie;
-	// |fl(o*ie) - o*ie| <= 2^-24 |o*ie| per axis, the FMA adds half an ulp of the (smaller) result: 2^-22 max|o*ie| covers both boxes' planes
-	r.ferr = 2.4e-7f * fmaxf(fmaxf(fabsf(r.oie.x), fabsf(r.oie.y)), fabsf(r.oie.z)) + 1e-30f;
-#endif
 	return r;
 }
 
@@ -297,29 +296,18 @@ __device__ __noinline__ bool traverse_ref(const DScene& S, const RayCtx& r, floa
 }
 
 // ---- primitive hierarchy + membership check (MODE_EXACT / MODE_FAST) -----------------------------------------------------
-// Conservative slab test for the hierarchy's own (padded) boxes: reciprocal multiply plus slack, never rejects a box the
-// exact arithmetic would accept.  tnear = entry parameter.
+// Slab test for the hierarchy's own boxes: t = b*(1/d) - o*(1/d) as one FMA per plane.  It must never reject a box that
+// contains a point the exact primitive tests can accept.  Its rounding error, mapped back to world space, is below
+// 2^-22 * (|o| + |b|) per axis; mirt_scene_create pads every box by 1e-5 * (|b| + D) with D >= |o|, two decimal orders
+// more, so the plain comparisons below are conservative without any run-time slack.  tnear = entry parameter.
 __device__ __forceinline__ bool box_filter(const RayCtx& r, const float4& lo, const float4& hi, float tcull, float& tnear) {
-#if MIRT_BOX_FMA
-	// t = lo*ie - o*ie in one FMA; its absolute error is bounded by r.ferr (set in make_ray), which widens the accept test
 	const float t1 = __builtin_fmaf(lo.x, r.ie.x, -r.oie.x), t2 = __builtin_fmaf(hi.x, r.ie.x, -r.oie.x);
 	const float t3 = __builtin_fmaf(lo.y, r.ie.y, -r.oie.y), t4 = __builtin_fmaf(hi.y, r.ie.y, -r.oie.y);
 	const float t5 = __builtin_fmaf(lo.z, r.ie.z, -r.oie.z), t6 = __builtin_fmaf(hi.z, r.ie.z, -r.oie.z);
-#else
-	const float t1 = (lo.x - r.o.x) * r.ie.x, t2 = (hi.x - r.o.x) * r.ie.x;
-	const float t3 = (lo.y - r.o.y) * r.ie.y, t4 = (hi.y - r.o.y) * r.ie.y;
-	const float t5 = (lo.z - r.o.z) * r.ie.z, t6 = (hi.z - r.o.z) * r.ie.z;
-#endif
 	const float tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
 	const float tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
 	tnear = tmin;
-#if MIRT_BOX_FMA
-	const float slack = 4e-6f * fmaxf(fabsf(tmin), fabsf(tmax)) + r.ferr;
-	return (tmin <= tmax + slack) && (tmax >= -r.ferr) && !(tmin - r.ferr > tcull);
-#else
-	const float slack = 4e-6f * fmaxf(fabsf(tmin), fabsf(tmax)) + 1e-30f;
-	return (tmin <= tmax + slack) && (tmax >= 0.0f) && !(tmin > tcull);
-#endif
+	return (tmin <= tmax) && (tmax >= 0.0f) && !(tmin > tcull);
 }
 
 // Is the primitive held by a reference leaf whose box the ray hits?  Returns the visiting rank of the first such
@@ -386,7 +374,11 @@ struct Walker {
 
 	// One round: descend to the next leaf, test its primitives, pop.  Returns false when the walk is over.
 	__device__ __forceinline__ bool advance(const DScene& S, LdsStack<OVF>& stk) {
+		STAT_WAVE(S, 6); // advance rounds (wave)
+		STAT_LANE(S, 7); // advance rounds (lanes)
 		while (!(cur & BVH_LEAF)) {
+			STAT_WAVE(S, 0); // node steps (wave iterations)
+			STAT_LANE(S, 1); // node steps (lanes)
 			const float4* nd = S.bvh + (size_t)cur * 4;
 			const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
 			const uint32_t lref = __float_as_uint(q0.w), rref = __float_as_uint(q1.w);
@@ -411,6 +403,8 @@ struct Walker {
 		const bool sph = (cur & BVH_SPHERES) != 0;
 		const bool any = limit >= 0.0f;
 		for (uint32_t k = 0; k < cnt; ++k) {
+			STAT_WAVE(S, 2); // primitive tests (wave iterations)
+			STAT_LANE(S, 3); // primitive tests (lanes)
 			const uint32_t idx = first + k;
 			float dist;
 			if (sph) {
@@ -426,6 +420,8 @@ struct Walker {
 			if (!cand) continue;
 			uint32_t pos = 0;
 			if (MODE == MODE_EXACT) {
+				STAT_WAVE(S, 4); // membership checks (wave)
+				STAT_LANE(S, 5); // membership checks (lanes)
 				const uint4 info = sph ? S.sphInfo[idx] : S.triInfo[idx];
 				pos = membership(S, r, info.z, info.w);
 			}

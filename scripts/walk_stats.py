@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-launch traversal event counts from a -DMIRT_STATS=1 build (MIRT_LIB=exp/libmirt_stats.so)."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from raytracer_amd.device import DeviceScene
+from raytracer_amd.scene import FlatScene
+name = sys.argv[1] if len(sys.argv) > 1 else "scene7"
+w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
+flat = FlatScene.load(os.path.join(ROOT, "tests", "golden", name + ".flat.npz"))
+names = ["node_wave", "node_lane", "prim_wave", "prim_lane", "memb_wave", "memb_lane", "round_wave", "round_lane"]
+def read(s):
+    out = {}
+    for i, n in enumerate(names):
+        v = C.c_uint64()
+        s.lib.mirt_scene_query(s.h, 100 + i, C.byref(v))
+        out[n] = v.value
+    return out
+with DeviceScene(flat, 0) as s:
+    read(s)
+    for feats, label in [(1 | 2, "primary only (no shadows, no reflections)"), (15, "all features")]:
+        _, st = s.render(w, h, features=feats)
+        c = read(s)
+        rays = st["primary_rays"] + (st["shadow_rays_traced"] + st["reflection_rays"] if feats == 15 else 0)
+        print(label, st)
+        print("  per ray: node steps %.1f, prim tests %.1f, membership %.2f, rounds %.1f" % (c["node_lane"] / rays, c["prim_lane"] / rays, c["memb_lane"] / rays, c["round_lane"] / rays))
+        for k in ("node", "prim", "memb", "round"):
+            print("  %-6s lane utilisation %.2f  (wave iterations %d)" % (k, c[k + "_lane"] / max(1, 64 * c[k + "_wave"]), c[k + "_wave"]))
