@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--trace-mode", choices=["exact", "fast"], default="exact")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo = rehearsal with ranks sharing a GPU)")
+    ap.add_argument("--pipeline", type=int, default=2, help="frames in flight (each on its own HIP stream and workspace)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=16)
     args = ap.parse_args()
@@ -102,19 +103,27 @@ def main():
     scene = DeviceScene(flat, dev_index)
     params = multigpu.rank_params(width, height, rank, world, trace_mode=trace_mode)
     nbytes = multigpu.per_rank_bytes(width, height, world) if world > 1 else width * height * 3
-    local = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
-    image = torch.empty(width * height * 3, dtype=torch.uint8, device="cuda") if (world > 1 and rank == 0) else None
+    # frames are issued round-robin on `pipeline` streams; the library keeps one workspace per stream, so the short
+    # latency-bound deep-bounce launches of one frame overlap the bulk of the next
+    depth = max(1, args.pipeline)
+    streams = [torch.cuda.Stream() for _ in range(depth)]
+    locals_ = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(depth)]
+    images = [torch.empty(width * height * 3, dtype=torch.uint8, device="cuda") for _ in range(depth)] if (world > 1 and rank == 0) else None
     gloo = world > 1 and args.backend == "gloo"
+    frame_no = [0]
 
     def step():
-        scene.render_device(params, local.data_ptr(), nbytes, stream)
-        if world > 1:
-            src = local.cpu() if gloo else local
-            got = multigpu.gather_to_root(src, world, rank, dist)
-            if rank == 0:
-                got = got.cuda() if gloo else got
-                scene.assemble_tiles(params, world, got.data_ptr(), nbytes, image.data_ptr(), stream)
+        k = frame_no[0] % depth
+        frame_no[0] += 1
+        st, local = streams[k], locals_[k]
+        with torch.cuda.stream(st):
+            scene.render_device(params, local.data_ptr(), nbytes, st.cuda_stream)
+            if world > 1:
+                src = local.cpu() if gloo else local
+                got = multigpu.gather_to_root(src, world, rank, dist)
+                if rank == 0:
+                    got = got.cuda() if gloo else got
+                    scene.assemble_tiles(params, world, got.data_ptr(), nbytes, images[k].data_ptr(), st.cuda_stream)
 
     def fence():
         torch.cuda.synchronize()
@@ -130,6 +139,8 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    stream = streams[(frame_no[0] - 1) % depth].cuda_stream
+    local = locals_[(frame_no[0] - 1) % depth]
     st = scene.stats(stream)
     rays_local = np.array([st["primary_rays"], st["shadow_rays"], st["reflection_rays"]], dtype=np.int64)
 
@@ -165,7 +176,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": "final_scenes/scene7 (Stanford Dragon, 100000 triangles, 1 point light) %dx%d maxdepth 5 diffuse+specular+shadows+reflections" % (width, height),
-                "trace_mode": args.trace_mode,
+                "trace_mode": args.trace_mode, "frames_in_flight": depth,
                 "parallelism": "single GPU, whole image" if world == 1 else "interleaved %dx%d tiles over %d GPUs, scene replicated, %s gather of packed tiles to rank 0" % (multigpu.TILE_W, multigpu.TILE_H, world, "RCCL" if not gloo else "gloo (rehearsal)"),
                 "scene_source": "flattened by the reference's own parser and Partition build (tests/golden/scene7.flat.npz)",
             },

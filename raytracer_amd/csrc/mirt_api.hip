@@ -72,6 +72,21 @@ inline h3 hnorm(h3 a) { float s = 1.0f / sqrtf(hdot(a, a)); return H3(a.x * s, a
 
 }  // namespace
 
+// Working set of the frames issued on one stream.  Frames on different streams own different workspaces, so they may
+// overlap on the GPU (the short, latency-bound deep-bounce launches of one frame run beside the bulk of the next).
+struct FrameCtx {
+	hipStream_t stream = nullptr;
+	Workspace ws;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	// last frame, for mirt_get_stats / mirt_get_launch_times
+	uint64_t lastPrimary = 0;
+	uint32_t lastFeatures = 0;
+	bool lastValid = false;
+	std::vector<hipEvent_t> launchEv;
+	std::vector<int32_t> launchKind;
+	uint32_t nLaunches = 0;
+};
+
 struct mirt_scene {
 	int device = 0;
 	int numCUs = 256;
@@ -80,21 +95,12 @@ struct mirt_scene {
 	bool nested = true;      // reference boxes nested: the primitive hierarchy may be used
 	uint32_t bvhDepth = 0;
 	bool deepBvh = false;    // hierarchy deeper than the LDS part of the traversal stack
-	Workspace ws;
 	hipStream_t stream = nullptr; // used by the synchronous entry points
-	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	uint32_t nLights = 0;
 	int32_t maxDepth = 0;
 	uint32_t wideDepth = 0;
-	// last asynchronous frame, for mirt_get_stats
-	uint64_t lastPrimary = 0;
-	uint32_t lastFeatures = 0;
-	bool lastValid = false;
-	// optional per-launch timing
+	std::vector<FrameCtx*> ctxs; // one per stream that has rendered with this scene
 	bool profiling = false;
-	std::vector<hipEvent_t> launchEv;
-	std::vector<int32_t> launchKind;
-	uint32_t nLaunches = 0;
 };
 
 namespace {
@@ -240,37 +246,50 @@ TileGeom tile_geom(const mirt_render_params* p, uint32_t tileW, uint32_t tileH) 
 
 bool packed_layout(const mirt_render_params* p) { return !(p->tile_stride == 1 && p->tile_w == 0 && p->tile_h == 0); }
 
+#define MIRT_MAX_STREAMS 8
+FrameCtx* ctx_for(mirt_scene* s, hipStream_t st, bool create) {
+	for (FrameCtx* c : s->ctxs) if (c->stream == st) return c;
+	if (!create) return nullptr;
+	if (s->ctxs.size() >= MIRT_MAX_STREAMS) { fail(MIRT_E_INVALID, "more than %d streams used with one scene", MIRT_MAX_STREAMS); return nullptr; }
+	FrameCtx* c = new (std::nothrow) FrameCtx();
+	if (!c) { fail(MIRT_E_NOMEM, "out of host memory"); return nullptr; }
+	c->stream = st;
+	if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { fail(MIRT_E_DEVICE, "hipEventCreate failed"); delete c; return nullptr; }
+	s->ctxs.push_back(c);
+	return c;
+}
+
 // a tree whose boxes are not nested is walked as it is, whatever mode was asked for
 int effective_mode(const mirt_scene* s, uint32_t mode) { return s->nested ? (int)mode : MODE_REFWALK; }
 
 // event after launch i (event 0 precedes the first launch); only when profiling is on
-void mark(mirt_scene* s, hipStream_t st, int kind) {
+void mark(mirt_scene* s, FrameCtx* c, hipStream_t st, int kind) {
 	if (!s->profiling) return;
-	const size_t need = (size_t)s->nLaunches + 2;
-	while (s->launchEv.size() < need) {
+	const size_t need = (size_t)c->nLaunches + 2;
+	while (c->launchEv.size() < need) {
 		hipEvent_t e = nullptr;
 		if (hipEventCreate(&e) != hipSuccess) { s->profiling = false; return; }
-		s->launchEv.push_back(e);
+		c->launchEv.push_back(e);
 	}
-	if (kind < 0) { (void)hipEventRecord(s->launchEv[0], st); return; }
-	s->launchKind.resize(s->nLaunches + 1);
-	s->launchKind[s->nLaunches] = kind;
-	(void)hipEventRecord(s->launchEv[s->nLaunches + 1], st);
-	s->nLaunches++;
+	if (kind < 0) { (void)hipEventRecord(c->launchEv[0], st); return; }
+	c->launchKind.resize(c->nLaunches + 1);
+	c->launchKind[c->nLaunches] = kind;
+	(void)hipEventRecord(c->launchEv[c->nLaunches + 1], st);
+	c->nLaunches++;
 }
 
 // One frame.  T(d) traces every ray of depth d in one launch: the reflection rays of that depth together with the shadow
 // queries of the hits of depth d-1; shade(d) evaluates the lights for the hits of depth d once those queries are answered:
 //     T(0) | T(1) shade(0) | T(2) shade(1) | ... | T(last+1: shadow queries only) shade(last) | resolve
 template <int MODE, bool OVF>
-void launch_frame(mirt_scene* s, const DFrame& F, uint8_t* out, hipStream_t st) {
+void launch_frame(mirt_scene* s, FrameCtx* c, const DFrame& F, uint8_t* out, hipStream_t st) {
 	const int grid = s->numCUs * GRID_BLOCKS_PER_CU;
 	const int sgrid = s->numCUs * 8;
 	int launch = 0;
-	s->nLaunches = 0;
-	mark(s, st, -1);
+	c->nLaunches = 0;
+	mark(s, c, st, -1);
 	hipLaunchKernelGGL((k_trace<MODE, OVF, true>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, out, 0, launch++, 0);
-	mark(s, st, MIRT_K_PRIMARY);
+	mark(s, c, st, MIRT_K_PRIMARY);
 	if (F.debug != D_PRIMARY_MAP) {
 		const int last = (F.features & F_REFLECTIONS) ? s->maxDepth : 0;
 		const bool shadowRays = (F.features & F_SHADOWS) && s->nLights > 0;
@@ -278,13 +297,13 @@ void launch_frame(mirt_scene* s, const DFrame& F, uint8_t* out, hipStream_t st) 
 			const int spawn = depth < last ? 1 : 0; // reflection rays exist while depth+1 <= maxDepth (main.cpp:177)
 			if (spawn || shadowRays) {
 				hipLaunchKernelGGL((k_trace<MODE, OVF, false>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, out, depth + 1, launch++, spawn);
-				mark(s, st, MIRT_K_TRACE);
+				mark(s, c, st, MIRT_K_TRACE);
 			}
 			hipLaunchKernelGGL(k_shade, dim3(sgrid), dim3(BLOCK), 0, st, s->ds, F, depth);
-			mark(s, st, MIRT_K_SHADE);
+			mark(s, c, st, MIRT_K_SHADE);
 		}
 		hipLaunchKernelGGL(k_resolve, dim3(sgrid), dim3(BLOCK), 0, st, F, out);
-		mark(s, st, MIRT_K_RESOLVE);
+		mark(s, c, st, MIRT_K_RESOLVE);
 	}
 }
 
@@ -298,14 +317,16 @@ int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 	if (d_out_bytes < need) return fail(MIRT_E_INVALID, "output buffer holds %zu bytes, %zu needed", d_out_bytes, need);
 	if (g.nSlots >= 0xffffffc0ull) return fail(MIRT_E_INVALID, "too many pixel slots for one launch");
 	HIPCHK(hipSetDevice(s->device));
-	s->lastValid = false;
-	if (g.nSlots == 0) { s->lastPrimary = 0; s->lastFeatures = p->feature_bits; return MIRT_OK; }
+	FrameCtx* c = ctx_for(s, st, true);
+	if (!c) return MIRT_E_INVALID;
+	c->lastValid = false;
+	if (g.nSlots == 0) { c->lastPrimary = 0; c->lastFeatures = p->feature_bits; return MIRT_OK; }
 	if (s->maxDepth < 0) {
 		// depth 0 already exceeds maxDepth: computePixelColor returns Color() for every pixel (main.cpp:177,199)
 		HIPCHK(hipMemsetAsync(d_out, 0, need, st));
 		return MIRT_OK;
 	}
-	Workspace& w = s->ws;
+	Workspace& w = c->ws;
 	const size_t n = (size_t)g.nSlots;
 	const size_t depths = (size_t)s->maxDepth + 1;
 	const size_t nl = s->nLights;
@@ -332,46 +353,48 @@ int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 	F.firstTile = p->first_tile; F.tileStride = p->tile_stride;
 	F.features = p->feature_bits; F.debug = p->debug_mode;
 	F.packedTiles = packed ? 1u : 0u;
-	HIPCHK(hipEventRecord(s->ev0, st));
+	HIPCHK(hipEventRecord(c->ev0, st));
 	HIPCHK(hipMemsetAsync(w.counters.p, 0, CTR_COUNT * 4, st));
 	switch (effective_mode(s, p->trace_mode)) {
 	case MODE_FAST:
-		if (s->deepBvh) launch_frame<MODE_FAST, true>(s, F, (uint8_t*)d_out, st);
-		else launch_frame<MODE_FAST, false>(s, F, (uint8_t*)d_out, st);
+		if (s->deepBvh) launch_frame<MODE_FAST, true>(s, c, F, (uint8_t*)d_out, st);
+		else launch_frame<MODE_FAST, false>(s, c, F, (uint8_t*)d_out, st);
 		break;
-	case MODE_REFWALK: launch_frame<MODE_REFWALK, false>(s, F, (uint8_t*)d_out, st); break;
+	case MODE_REFWALK: launch_frame<MODE_REFWALK, false>(s, c, F, (uint8_t*)d_out, st); break;
 	default:
-		if (s->deepBvh) launch_frame<MODE_EXACT, true>(s, F, (uint8_t*)d_out, st);
-		else launch_frame<MODE_EXACT, false>(s, F, (uint8_t*)d_out, st);
+		if (s->deepBvh) launch_frame<MODE_EXACT, true>(s, c, F, (uint8_t*)d_out, st);
+		else launch_frame<MODE_EXACT, false>(s, c, F, (uint8_t*)d_out, st);
 		break;
 	}
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(s->ev1, st));
-	s->lastPrimary = g.livePixels;
-	s->lastFeatures = p->feature_bits;
-	s->lastValid = true;
+	HIPCHK(hipEventRecord(c->ev1, st));
+	c->lastPrimary = g.livePixels;
+	c->lastFeatures = p->feature_bits;
+	c->lastValid = true;
 	return MIRT_OK;
 }
 
 int read_stats(mirt_scene* s, hipStream_t st, mirt_stats* out) {
 	memset(out, 0, sizeof *out);
 	HIPCHK(hipStreamSynchronize(st));
-	out->primary_rays = s->lastPrimary;
-	if (!s->lastValid) return MIRT_OK;
-	uint32_t c[CTR_COUNT];
-	HIPCHK(hipMemcpy(c, s->ws.counters.p, sizeof c, hipMemcpyDeviceToHost));
+	FrameCtx* c = ctx_for(s, st, false);
+	if (!c) return MIRT_OK;
+	out->primary_rays = c->lastPrimary;
+	if (!c->lastValid) return MIRT_OK;
+	uint32_t cnt[CTR_COUNT];
+	HIPCHK(hipMemcpy(cnt, c->ws.counters.p, sizeof cnt, hipMemcpyDeviceToHost));
 	uint64_t hits = 0, refl = 0;
-	for (int d = 0; d <= s->maxDepth; ++d) hits += c[CTR_NHITS(d)];
+	for (int d = 0; d <= s->maxDepth; ++d) hits += cnt[CTR_NHITS(d)];
 	// a reflection ray is traced for every hit at depth d < maxDepth when REFLECTIONS is on (main.cpp:177,189-190)
-	if (s->lastFeatures & MIRT_F_REFLECTIONS) for (int d = 0; d < s->maxDepth; ++d) refl += c[CTR_NHITS(d)];
-	out->primary_hits = c[CTR_NHITS(0)];
+	if (c->lastFeatures & MIRT_F_REFLECTIONS) for (int d = 0; d < s->maxDepth; ++d) refl += cnt[CTR_NHITS(d)];
+	out->primary_hits = cnt[CTR_NHITS(0)];
 	out->shadow_rays = hits * s->nLights; // main.cpp:208-223: one query per light per hit, whatever the feature bits
 	uint64_t traced = 0;
-	for (int d = 0; d <= s->maxDepth; ++d) traced += c[CTR_NSHADOW(d)];
+	for (int d = 0; d <= s->maxDepth; ++d) traced += cnt[CTR_NSHADOW(d)];
 	out->shadow_rays_traced = traced;
 	out->reflection_rays = out->reflection_rays_traced = refl;
 	float ms = 0.0f;
-	HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+	HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
 	out->device_ms = ms;
 	return MIRT_OK;
 }
@@ -671,7 +694,6 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		ds.ovf = (uint32_t*)s->ovf.p;
 	}
 	if (!e && hipStreamCreate(&s->stream) != hipSuccess) e = fail(MIRT_E_DEVICE, "hipStreamCreate failed");
-	if (!e && (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess)) e = fail(MIRT_E_DEVICE, "hipEventCreate failed");
 	if (e) {
 		std::string keep = g_err;
 		mirt_scene_destroy(s);
@@ -698,10 +720,14 @@ void mirt_scene_destroy(mirt_scene* s) {
 	if (s->stream) (void)hipStreamSynchronize(s->stream);
 	s->nodes.release(); s->leafs.release(); s->bvh.release(); s->memb.release(); s->tris.release(); s->triInfo.release();
 	s->spheres.release(); s->sphInfo.release(); s->materials.release(); s->lights.release(); s->ovf.release(); s->dbg.release();
-	s->ws.release();
-	if (s->ev0) (void)hipEventDestroy(s->ev0);
-	if (s->ev1) (void)hipEventDestroy(s->ev1);
-	for (hipEvent_t e : s->launchEv) (void)hipEventDestroy(e);
+	for (FrameCtx* c : s->ctxs) {
+		(void)hipStreamSynchronize(c->stream);
+		c->ws.release();
+		if (c->ev0) (void)hipEventDestroy(c->ev0);
+		if (c->ev1) (void)hipEventDestroy(c->ev1);
+		for (hipEvent_t e : c->launchEv) (void)hipEventDestroy(e);
+		delete c;
+	}
 	if (s->stream) (void)hipStreamDestroy(s->stream);
 	delete s;
 }
@@ -751,7 +777,7 @@ int mirt_scene_query(mirt_scene* s, uint32_t what, uint64_t* v) {
 int mirt_set_profiling(mirt_scene* s, int enabled) {
 	if (!s) return fail(MIRT_E_INVALID, "scene handle is NULL");
 	s->profiling = enabled != 0;
-	s->nLaunches = 0;
+	for (FrameCtx* c : s->ctxs) c->nLaunches = 0;
 	return MIRT_OK;
 }
 
@@ -761,9 +787,11 @@ int mirt_get_launch_times(mirt_scene* s, void* hip_stream, float* ms_out, int32_
 	HIPCHK(hipStreamSynchronize((hipStream_t)hip_stream));
 	*n_out = 0;
 	if (!s->profiling) return fail(MIRT_E_INVALID, "profiling is off (mirt_set_profiling)");
-	for (uint32_t i = 0; i < s->nLaunches && i < capacity; ++i) {
-		HIPCHK(hipEventElapsedTime(&ms_out[i], s->launchEv[i], s->launchEv[i + 1]));
-		kinds_out[i] = s->launchKind[i];
+	FrameCtx* c = ctx_for(s, (hipStream_t)hip_stream, false);
+	if (!c) return MIRT_OK;
+	for (uint32_t i = 0; i < c->nLaunches && i < capacity; ++i) {
+		HIPCHK(hipEventElapsedTime(&ms_out[i], c->launchEv[i], c->launchEv[i + 1]));
+		kinds_out[i] = c->launchKind[i];
 		*n_out = i + 1;
 	}
 	return MIRT_OK;
@@ -785,15 +813,17 @@ int mirt_render(mirt_scene* s, const mirt_render_params* p, uint8_t* bgr_out, mi
 	const TileGeom g = tile_geom(p, tileW, tileH);
 	const size_t bytes = whole ? (size_t)p->width * p->height * 3 : (size_t)g.nSlots * 3;
 	if (bytes == 0) { if (stats) memset(stats, 0, sizeof *stats); return MIRT_OK; }
-	if ((e = s->ws.out.ensure(bytes))) return e;
-	if ((e = render_async(s, p, s->ws.out.p, bytes, s->stream, !whole))) return e;
+	FrameCtx* c = ctx_for(s, s->stream, true);
+	if (!c) return MIRT_E_INVALID;
+	if ((e = c->ws.out.ensure(bytes))) return e;
+	if ((e = render_async(s, p, c->ws.out.p, bytes, s->stream, !whole))) return e;
 	if (whole) {
-		HIPCHK(hipMemcpyAsync(bgr_out, s->ws.out.p, bytes, hipMemcpyDeviceToHost, s->stream));
+		HIPCHK(hipMemcpyAsync(bgr_out, c->ws.out.p, bytes, hipMemcpyDeviceToHost, s->stream));
 		HIPCHK(hipStreamSynchronize(s->stream));
 	}
 	else {
 		std::vector<uint8_t> tmp(bytes);
-		HIPCHK(hipMemcpyAsync(tmp.data(), s->ws.out.p, bytes, hipMemcpyDeviceToHost, s->stream));
+		HIPCHK(hipMemcpyAsync(tmp.data(), c->ws.out.p, bytes, hipMemcpyDeviceToHost, s->stream));
 		HIPCHK(hipStreamSynchronize(s->stream));
 		for (uint32_t lt = 0; lt < g.nLocal; ++lt) {
 			const uint64_t k = p->first_tile + (uint64_t)lt * p->tile_stride;
