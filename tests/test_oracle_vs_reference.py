@@ -1,0 +1,84 @@
+"""CPU: the C restatement against the reference's own compiled classes (oracle/_ref/libref_oracle.so), live, on inputs
+the committed fixtures do not hold: other resolutions, random rays, every primitive of the small scenes.
+Skipped where the reference build is absent (it is produced by `make -C oracle ref` where /root/reference exists and
+travels with the tree to the GPU box)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, bits
+from oracle.bind import CPort, REF_LIB, RefOracle
+
+pytestmark = pytest.mark.skipif(not os.path.exists(REF_LIB), reason="reference build oracle/_ref not present")
+
+
+def _scene_file(name, w, h, tmp_path):
+    lines = open(os.path.join(GOLDEN, "scenes", name + ".test")).read().split("\n")
+    lines = ["size %d %d" % (w, h) if ln.strip().startswith("size ") else ln for ln in lines]
+    p = tmp_path / (name + ".test")
+    p.write_text("\n".join(lines))
+    return str(p)
+
+
+@pytest.mark.parametrize("name,size", [("scene1", (97, 61)), ("scene2", (120, 160)), ("scene4-specular", (200, 150)),
+                                       ("scene5", (128, 72)), ("scene6", (80, 60))])
+def test_flatten_trace_render_match_reference(name, size, tmp_path, flat_scenes):
+    w, h = size
+    ref = RefOracle(_scene_file(name, w, h, tmp_path))
+    fs = ref.flatten()
+    committed = flat_scenes(name)
+    # the committed flattened scene is the reference's tree, whatever the image size
+    assert np.array_equal(fs.nodes, committed.nodes) and np.array_equal(fs.leaf_prims, committed.leaf_prims)
+    port = CPort(fs)
+    o, d = ref.primary_rays(w, h)
+    o2, d2 = port.primary_rays(w, h)
+    assert np.array_equal(bits(o), bits(o2)) and np.array_equal(bits(d), bits(d2))
+    ids, dist, nrm, vis = ref.trace(o, d)
+    ids2, dist2, nrm2, vis2 = port.trace(o, d)
+    assert np.array_equal(ids, ids2) and np.array_equal(bits(dist), bits(dist2)) and np.array_equal(vis, vis2)
+    assert np.array_equal(bits(nrm[ids >= 0]), bits(nrm2[ids >= 0]))
+    img, st = ref.render(w, h)
+    img2, st2 = port.render(w, h)
+    assert np.array_equal(img, img2)
+    assert [st["primary"], st["shadow"], st["reflection"]] == [st2["primary_rays"], st2["shadow_rays"], st2["reflection_rays"]]
+    ref.close()
+
+
+def test_random_rays_against_dragon(tmp_path, flat_scenes):
+    ref = RefOracle(_scene_file("scene7", 64, 48, tmp_path))
+    port = CPort(flat_scenes("scene7"))
+    rng = np.random.default_rng(7)
+    n = 3000
+    o = rng.uniform(-9, 9, size=(n, 3)).astype(np.float32)
+    tgt = rng.uniform(-4, 4, size=(n, 3)).astype(np.float32)
+    d = (tgt - o).astype(np.float32)
+    d[::2] /= np.linalg.norm(d[::2], axis=1, keepdims=True).astype(np.float32)
+    d[5::50, 0] = 0.0          # exactly axis-parallel components
+    d[7::50, 1] = 3e-6         # below the 1e-5 substitution of AABB.cpp:53-58
+    ids, dist, nrm, vis = ref.trace(o, d)
+    ids2, dist2, nrm2, vis2 = port.trace(o, d)
+    assert (ids >= 0).sum() > 100
+    assert np.array_equal(ids, ids2) and np.array_equal(bits(dist), bits(dist2)) and np.array_equal(vis, vis2)
+    ref.close()
+
+
+def test_every_primitive_of_small_scenes(tmp_path):
+    rng = np.random.default_rng(3)
+    for name in ("scene1", "scene2", "scene6"):
+        ref = RefOracle(_scene_file(name, 32, 24, tmp_path))
+        fs = ref.flatten()
+        port = CPort(fs)
+        o = rng.uniform(-3, 3, size=(400, 3)).astype(np.float32)
+        d = rng.normal(size=(400, 3)).astype(np.float32)
+        for p in range(fs.n_prims):
+            want, wn = ref.prim_intersect(p, o, d)
+            tri = np.flatnonzero(fs.tri_prim == p)
+            if tri.size:
+                got, gn = port.triangle(fs.tri_verts[tri[0]], o, d)
+            else:
+                got, gn = port.sphere(fs.spheres[np.flatnonzero(fs.sphere_prim == p)[0]], o, d)
+            assert np.array_equal(bits(want), bits(got)), (name, p)
+            hit = ~np.isinf(want)
+            assert np.array_equal(bits(wn[hit]), bits(gn[hit])), (name, p)
+        ref.close()
