@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--trace-mode", choices=["exact", "fast"], default="exact")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo = rehearsal with ranks sharing a GPU)")
-    ap.add_argument("--pipeline", type=int, default=2, help="frames in flight (each on its own HIP stream and workspace)")
+    ap.add_argument("--pipeline", type=int, default=0, help="frames in flight (each on its own HIP stream and workspace)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=16)
     args = ap.parse_args()
@@ -105,7 +105,7 @@ def main():
     nbytes = multigpu.per_rank_bytes(width, height, world) if world > 1 else width * height * 3
     # frames are issued round-robin on `pipeline` streams; the library keeps one workspace per stream, so the short
     # latency-bound deep-bounce launches of one frame overlap the bulk of the next
-    depth = max(1, args.pipeline)
+    depth = args.pipeline if args.pipeline > 0 else (2 if world == 1 else 4)
     streams = [torch.cuda.Stream() for _ in range(depth)]
     locals_ = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(depth)]
     images = [torch.empty(width * height * 3, dtype=torch.uint8, device="cuda") for _ in range(depth)] if (world > 1 and rank == 0) else None
@@ -134,6 +134,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    scene.set_profiling(True)  # HIP events around every launch, recorded on the launch stream itself
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -144,16 +145,19 @@ def main():
     st = scene.stats(stream)
     rays_local = np.array([st["primary_rays"], st["shadow_rays"], st["reflection_rays"]], dtype=np.int64)
 
-    # per-kernel device time of one more frame (HIP events on the launch stream), outside the timed region
-    scene.set_profiling(True)
-    per_kernel = {}
-    reps = 5
-    for _ in range(reps):
-        scene.render_device(params, local.data_ptr(), nbytes, stream)
-        for name, ms in scene.launch_times(stream):
-            per_kernel.setdefault(name, []).append(ms)
+    def collect(frames):
+        acc = {}
+        for lt in frames:
+            for name, ms in lt:
+                acc.setdefault(name, []).append(ms)
+        nf = max(1, len(frames))
+        return {k: {"launches_per_frame": len(v) // nf, "ms_per_frame": sum(v) / nf, "avg_launch_ms": sum(v) / len(v)} for k, v in acc.items()}
+
+    # (a) launch durations INSIDE the timed region: the last frame of every stream (frames overlap, so a launch shares the GPU)
+    kern = collect([scene.launch_times(s_.cuda_stream) for s_ in streams[:min(depth, args.steps)]])
+    # (b) the same launches with nothing else on the GPU, outside the timed region
+    kern_alone = collect([(scene.render_device(params, local.data_ptr(), nbytes, stream), scene.launch_times(stream))[1] for _ in range(5)])
     scene.set_profiling(False)
-    kern = {k: {"launches_per_frame": len(v) // reps, "ms_per_frame": sum(v) / reps, "avg_launch_ms": sum(v) / len(v)} for k, v in per_kernel.items()}
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo else "cuda")
@@ -182,6 +186,7 @@ def main():
             },
             "rays_per_frame": {"primary": int(rays[0]), "shadow": int(rays[1]), "reflection": int(rays[2])},
             "kernels": kern,
+            "kernels_alone": kern_alone,
         }
         frame_ms = sum(k["ms_per_frame"] for k in kern.values())
         out["device_ms_per_frame"] = frame_ms
@@ -197,11 +202,16 @@ def main():
             # dominant kernels: everything that walks the tree (primary + trace + shade); resolve is the remainder
             walk_ms = sum(kern[k]["ms_per_frame"] for k in ("primary", "trace", "shade") if k in kern)
             achieved = frame_bytes / (walk_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01", "hbm_traffic.json")
+            if os.path.exists(tpath):  # PMC counters cannot be read from inside this process; separate rocprofv3 --pmc passes
+                traffic = json.load(open(tpath))["hbm_bytes_per_frame"]
             out["roofline"] = {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "tree-walking kernels of one frame (k_primary + k_trace + k_shade), %d launches" % sum(kern[k]["launches_per_frame"] for k in ("primary", "trace", "shade") if k in kern),
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "k_trace (+ k_shade): the launches of one frame that walk the scene, %d launches; durations = HIP events in the timed region" % sum(kern[k]["launches_per_frame"] for k in ("primary", "trace", "shade") if k in kern),
                 "algorithmic_bytes_per_ray": {"primary": per_ray[0], "shadow": per_ray[1], "reflection": per_ray[2]},
                 "algorithmic_bytes_per_frame": frame_bytes,
+                "traffic_note": "HBM bytes of one frame from rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/r01/hbm_traffic.json",
                 "note": "bytes = reference-semantics exhaustive walk (box tests x32 B + triangle tests x40 B + 32 B ray state); the device walk is ordered and culled, so it touches far fewer",
             }
         print(json.dumps(out), flush=True)

@@ -788,6 +788,7 @@ int mirt_get_launch_times(mirt_scene* s, void* hip_stream, float* ms_out, int32_
 	*n_out = 0;
 	if (!s->profiling) return fail(MIRT_E_INVALID, "profiling is off (mirt_set_profiling)");
 	FrameCtx* c = ctx_for(s, (hipStream_t)hip_stream, false);
+	if (!c && !hip_stream) c = ctx_for(s, s->stream, false); // NULL also names the stream of the synchronous mirt_render
 	if (!c) return MIRT_OK;
 	for (uint32_t i = 0; i < c->nLaunches && i < capacity; ++i) {
 		HIPCHK(hipEventElapsedTime(&ms_out[i], c->launchEv[i], c->launchEv[i + 1]));

@@ -33,10 +33,15 @@ struct BvhNode {
 
 struct BvhBuilder {
 	static const int BINS = 16;
-#ifndef MIRT_LEAF_MAX
-#define MIRT_LEAF_MAX 4
+#ifndef MIRT_LEAF_MIN
+#define MIRT_LEAF_MIN 2
 #endif
-	static const uint32_t LEAF_MAX = MIRT_LEAF_MAX;
+#ifndef MIRT_COST_PRIM
+#define MIRT_COST_PRIM 1.5f
+#endif
+	static const uint32_t LEAF_MIN = MIRT_LEAF_MIN; // ranges this small always become a leaf
+	static const uint32_t LEAF_CAP = 8;             // a leaf reference holds a 3-bit count
+	static constexpr float COST_NODE = 1.0f, COST_PRIM = MIRT_COST_PRIM;
 	static const int SAH_DEPTH = 28; // below this depth splits are balanced medians, which bounds the total depth
 
 	std::vector<BvhPrim> prims; // reordered in place: leaf ranges are contiguous
@@ -76,59 +81,69 @@ struct BvhBuilder {
 		n.count = end - start;
 		n.kind = prims[start].kind;
 		const uint32_t cnt = end - start;
-		if (cnt <= LEAF_MAX && !mixed) { nodes[me] = n; return me; }
+		if (cnt <= LEAF_MIN && !mixed) { nodes[me] = n; return me; }
 
 		uint32_t mid = start;
-		if (mixed && cnt <= LEAF_MAX) {
+		if (mixed && cnt <= LEAF_MIN) {
 			// small mixed range: split by kind so that every leaf holds one kind of primitive
 			mid = (uint32_t)(std::partition(prims.begin() + start, prims.begin() + end, [](const BvhPrim& p) { return p.kind == 0; }) - prims.begin());
 		}
 		else {
+			// binned SAH over all three axes; the split must beat the cost of testing the range as one leaf
 			int axis = 0;
 			float ext = chi[0] - clo[0];
 			for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > ext) { ext = chi[k] - clo[k]; axis = k; }
 			bool done = false;
 			if (ext > 0.0f && depth < (uint32_t)SAH_DEPTH) {
-				// binned SAH on the axis of largest centroid extent
-				uint32_t bc[BINS] = {0};
-				float blo[BINS][3], bhi[BINS][3];
-				for (int b = 0; b < BINS; ++b) for (int k = 0; k < 3; ++k) { blo[b][k] = INFINITY; bhi[b][k] = -INFINITY; }
-				const float scale = (float)BINS / ext;
-				for (uint32_t i = start; i < end; ++i) {
-					const float c = 0.5f * (prims[i].lo[axis] + prims[i].hi[axis]);
-					int b = (int)((c - clo[axis]) * scale);
-					b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
-					bc[b]++;
-					grow(blo[b], bhi[b], prims[i].lo, prims[i].hi);
-				}
-				float rightArea[BINS];
-				uint32_t rightCnt[BINS];
-				float rlo[3] = {INFINITY, INFINITY, INFINITY}, rhi[3] = {-INFINITY, -INFINITY, -INFINITY};
-				uint32_t rc = 0;
-				for (int b = BINS - 1; b > 0; --b) {
-					if (bc[b]) grow(rlo, rhi, blo[b], bhi[b]);
-					rc += bc[b];
-					rightArea[b] = rc ? area(rlo, rhi) : 0.0f;
-					rightCnt[b] = rc;
-				}
-				float llo[3] = {INFINITY, INFINITY, INFINITY}, lhi[3] = {-INFINITY, -INFINITY, -INFINITY};
-				uint32_t lc = 0;
-				float bestCost = INFINITY;
-				int bestBin = -1;
-				for (int b = 0; b < BINS - 1; ++b) {
-					if (bc[b]) grow(llo, lhi, blo[b], bhi[b]);
-					lc += bc[b];
-					if (lc == 0 || rightCnt[b + 1] == 0) continue;
-					const float cost = area(llo, lhi) * (float)lc + rightArea[b + 1] * (float)rightCnt[b + 1];
-					if (cost < bestCost) { bestCost = cost; bestBin = b; }
+				float bestCost = INFINITY, bestScale = 0.0f;
+				int bestBin = -1, bestAxis = -1;
+				for (int ax = 0; ax < 3; ++ax) {
+					const float e = chi[ax] - clo[ax];
+					if (!(e > 0.0f)) continue;
+					uint32_t bc[BINS] = {0};
+					float blo[BINS][3], bhi[BINS][3];
+					for (int b = 0; b < BINS; ++b) for (int k = 0; k < 3; ++k) { blo[b][k] = INFINITY; bhi[b][k] = -INFINITY; }
+					const float scale = (float)BINS / e;
+					for (uint32_t i = start; i < end; ++i) {
+						const float c = 0.5f * (prims[i].lo[ax] + prims[i].hi[ax]);
+						int b = (int)((c - clo[ax]) * scale);
+						b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+						bc[b]++;
+						grow(blo[b], bhi[b], prims[i].lo, prims[i].hi);
+					}
+					float rightArea[BINS];
+					uint32_t rightCnt[BINS];
+					float rlo[3] = {INFINITY, INFINITY, INFINITY}, rhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+					uint32_t rc = 0;
+					for (int b = BINS - 1; b > 0; --b) {
+						if (bc[b]) grow(rlo, rhi, blo[b], bhi[b]);
+						rc += bc[b];
+						rightArea[b] = rc ? area(rlo, rhi) : 0.0f;
+						rightCnt[b] = rc;
+					}
+					float llo[3] = {INFINITY, INFINITY, INFINITY}, lhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+					uint32_t lc = 0;
+					for (int b = 0; b < BINS - 1; ++b) {
+						if (bc[b]) grow(llo, lhi, blo[b], bhi[b]);
+						lc += bc[b];
+						if (lc == 0 || rightCnt[b + 1] == 0) continue;
+						const float cost = area(llo, lhi) * (float)lc + rightArea[b + 1] * (float)rightCnt[b + 1];
+						if (cost < bestCost) { bestCost = cost; bestBin = b; bestAxis = ax; bestScale = scale; }
+					}
 				}
 				if (bestBin >= 0) {
-					const float ca = clo[axis];
+					// leaf cost n*Ci against split cost Ct + (children cost)/area(node); Ci/Ct from the kernel's instruction counts
+					const float nodeArea = area(lo, hi);
+					const float splitCost = COST_NODE + COST_PRIM * bestCost / (nodeArea > 0.0f ? nodeArea : 1.0f);
+					if (cnt <= LEAF_CAP && !mixed && (float)cnt * COST_PRIM <= splitCost) { nodes[me] = n; return me; }
+					const int ax = bestAxis;
+					const float ca = clo[ax], scale = bestScale;
+					const int bb = bestBin;
 					mid = (uint32_t)(std::partition(prims.begin() + start, prims.begin() + end, [=](const BvhPrim& p) {
-						const float c = 0.5f * (p.lo[axis] + p.hi[axis]);
+						const float c = 0.5f * (p.lo[ax] + p.hi[ax]);
 						int b = (int)((c - ca) * scale);
 						b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
-						return b <= bestBin;
+						return b <= bb;
 					}) - prims.begin());
 					done = mid > start && mid < end;
 				}
