@@ -1,4 +1,4 @@
-"""ctypes mirror of include/mirt.h and loader of the HIP library (libmirt.so).
+"""ctypes mirror of include/mirt.h + include/mirt_host.h and loader of the HIP library (libmirt.so).
 
 The product path has no CPU fallback: if libmirt.so is missing or fails to load, importing
 ``raytracer_amd.device`` raises.  This module only declares the ABI; it performs no arithmetic.
@@ -97,6 +97,14 @@ SYMBOLS = [
     ("mirt_trace_rays", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mirt_trace_primary_ids", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("mirt_last_error", C.c_char_p, []),
+    # include/mirt_host.h
+    ("mirt_host_scene_load", C.c_int, [C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("mirt_host_scene_parse", C.c_int, [C.c_char_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("mirt_host_scene_from_prims", C.c_int, [C.POINTER(SceneDesc), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("mirt_host_scene_desc", C.c_int, [C.c_void_p, C.POINTER(SceneDesc), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("mirt_host_scene_output_name", C.c_char_p, [C.c_void_p]),
+    ("mirt_host_scene_timing", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("mirt_host_scene_destroy", None, [C.c_void_p]),
 ]
 
 _lib = None

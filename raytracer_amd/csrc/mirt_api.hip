@@ -3,6 +3,7 @@
 #include "../../include/mirt.h"
 #include "mirt_kernels.hip"
 #include "mirt_bvh.h"
+#include "mirt_internal.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -30,6 +31,20 @@ int fail(int code, const char* fmt, ...) {
 	g_err = buf;
 	return code;
 }
+
+} // namespace
+
+int mirt_set_error(int code, const char* fmt, ...) {
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	g_err = buf;
+	return code;
+}
+
+namespace {
 
 #define HIPCHK(expr)                                                                                          \
 	do {                                                                                                      \

@@ -356,10 +356,18 @@ struct Walker {
 	Hit best;
 	uint32_t cur;
 	int sp;
+	// MODE_EXACT: a hit counts only if a reference leaf holding the primitive is box-hit (membership()).  Checking that
+	// at every candidate runs at ~6 % lane utilisation, so the walk normally defers it: it keeps the nearest candidate
+	// unverified and the caller verifies the final answer once (verify()), many lanes at a time.  Only if that check
+	// fails, or two different primitives tie in distance (the rank decides, Partition.h:33 / Partition.cpp:47), is the
+	// ray walked again in strict mode, where every candidate is checked on the spot.
+	bool strict, needStrict;
 
-	__device__ __forceinline__ bool start(const DScene& S, f3 o, f3 d, float lim) {
+	__device__ __forceinline__ bool start(const DScene& S, f3 o, f3 d, float lim, bool strictMode = false) {
 		r = make_ray(o, d);
 		limit = lim;
+		strict = strictMode || MODE != MODE_EXACT;
+		needStrict = false;
 		best.dist = __builtin_inff();
 		best.ref = REF_NONE;
 		best.pos = 0xffffffffu;
@@ -416,16 +424,22 @@ struct Walker {
 			}
 			if (!(dist >= 0.0f) || isinf(dist)) continue;
 			const uint32_t ref = sph ? (PRIM_SPHERE | idx) : idx;
-			const bool cand = any ? (dist < limit) : (dist < best.dist || (dist == best.dist && ref != best.ref));
+			const bool tie = !any && dist == best.dist && ref != best.ref;
+			const bool cand = any ? (dist < limit) : (dist < best.dist || tie);
 			if (!cand) continue;
 			uint32_t pos = 0;
 			if (MODE == MODE_EXACT) {
-				STAT_WAVE(S, 4); // membership checks (wave)
-				STAT_LANE(S, 5); // membership checks (lanes)
-				const uint4 info = sph ? S.sphInfo[idx] : S.triInfo[idx];
-				pos = membership(S, r, info.z, info.w);
+				if (!strict) {
+					if (tie) { needStrict = true; cur = BVH_DONE; return false; }
+				}
+				else {
+					STAT_WAVE(S, 4); // membership checks (wave)
+					STAT_LANE(S, 5); // membership checks (lanes)
+					const uint4 info = sph ? S.sphInfo[idx] : S.triInfo[idx];
+					pos = membership(S, r, info.z, info.w);
+					if (pos == REF_NONE) continue; // the reference's tree never reaches this primitive along this ray
+				}
 			}
-			if (pos == REF_NONE) continue; // the reference's tree never reaches this primitive along this ray
 			if (any) {
 				best.dist = dist;
 				best.ref = ref;
@@ -445,6 +459,17 @@ struct Walker {
 		cur = stk.pop(--sp);
 		return true;
 	}
+
+	// After a deferred walk has ended: is its answer final?  false = walk the ray again with start(..., strict = true).
+	__device__ __forceinline__ bool verify(const DScene& S) const {
+		if (strict) return true;
+		if (needStrict) return false;
+		if (best.ref == REF_NONE) return true;
+		STAT_WAVE(S, 4);
+		STAT_LANE(S, 5);
+		const uint4 info = (best.ref & PRIM_SPHERE) ? S.sphInfo[best.ref & ~PRIM_SPHERE] : S.triInfo[best.ref];
+		return membership(S, r, info.z, info.w) != REF_NONE;
+	}
 };
 
 // whole walk at once (test hooks and MODE_REFWALK dispatch)
@@ -459,6 +484,10 @@ __device__ __forceinline__ void trace_whole(const DScene& S, f3 o, f3 d, float l
 	Walker<MODE == MODE_REFWALK ? MODE_EXACT : MODE, OVF> w;
 	bool alive = w.start(S, o, d, limit);
 	while (alive) alive = w.advance(S, stk);
+	if (!w.verify(S)) {
+		alive = w.start(S, o, d, limit, true);
+		while (alive) alive = w.advance(S, stk);
+	}
 	best = w.best;
 }
 
@@ -592,9 +621,14 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DScene S, DFrame F, uint8_t* __
 	uint32_t tag = 0;
 	uint32_t nShadowTraced = 0;
 	for (;;) {
-		const unsigned long long idle = __ballot(!alive);
-		const int nIdle = __popcll(idle);
-		if (nIdle >= MIRT_REFILL_MIN || sup.exhausted()) {
+		if (__popcll(__ballot(!alive)) >= MIRT_REFILL_MIN || sup.exhausted()) {
+			// (0) parked lanes make their answer final; the rare ray that fails the check is walked again, strictly
+			if (MODE == MODE_EXACT && parked && !w.verify(S)) {
+				alive = w.start(S, w.r.o, w.r.d, w.limit, true);
+				parked = !alive;
+			}
+			const unsigned long long idle = __ballot(!alive);
+			const int nIdle = __popcll(idle);
 			// (1) parked lanes write their results
 			bool newHit = false;
 			if (parked) {

@@ -80,6 +80,66 @@ class FlatScene:
         d.attenuation[:] = self.attenuation.tolist()
         return d
 
+    # ---- the library's own scene loader (include/mirt_host.h) ------------------------------------------
+    @classmethod
+    def _from_host_handle(cls, lib, h):
+        try:
+            d = _capi.SceneDesc()
+            w, hgt = C.c_uint32(0), C.c_uint32(0)
+            if lib.mirt_host_scene_desc(h, C.byref(d), C.byref(w), C.byref(hgt)) != 0:
+                raise RuntimeError(lib.mirt_last_error().decode())
+
+            def arr(ptr, dtype, count):
+                dt = np.dtype(dtype)
+                if not count:
+                    return np.zeros(0, dt)
+                buf = (C.c_char * (count * dt.itemsize)).from_address(ptr)
+                return np.frombuffer(buf, dtype=dt, count=count).copy()
+
+            cam = np.array(list(d.camera.look_from) + list(d.camera.look_at) + list(d.camera.up) + [d.camera.fovy_deg], np.float32)
+            fs = cls(w.value, hgt.value, d.max_depth,
+                     nodes=arr(d.nodes, NODE_DTYPE, d.n_nodes), leaf_prims=arr(d.leaf_prims, np.uint32, d.n_leaf_prims),
+                     tri_verts=arr(d.tri_verts, np.float32, d.n_triangles * 9), tri_prim=arr(d.tri_prim, np.uint32, d.n_triangles),
+                     spheres=arr(d.spheres, np.float32, d.n_spheres * 36), sphere_prim=arr(d.sphere_prim, np.uint32, d.n_spheres),
+                     prim_material=arr(d.prim_material, np.uint32, d.n_prims), materials=arr(d.materials, np.float32, d.n_materials * 13),
+                     lights=arr(d.lights, np.float32, d.n_lights * 8), camera=cam,
+                     attenuation=np.array(list(d.attenuation), np.float32))
+            ps, bs = C.c_double(0), C.c_double(0)
+            lib.mirt_host_scene_timing(h, C.byref(ps), C.byref(bs))
+            fs.parse_seconds, fs.build_seconds = ps.value, bs.value
+            fs.output_name = lib.mirt_host_scene_output_name(h).decode()
+            return fs
+        finally:
+            lib.mirt_host_scene_destroy(h)
+
+    @classmethod
+    def from_file(cls, path, threads=0):
+        """Parse a scene file in the reference's text format and build its Partition tree (Scene.cpp:15-224,
+        Partition.cpp:4-14) with the library's host-side loader."""
+        lib = _capi.load_library()
+        h = C.c_void_p()
+        if lib.mirt_host_scene_load(str(path).encode(), threads, C.byref(h)) != 0:
+            raise ValueError(lib.mirt_last_error().decode())
+        return cls._from_host_handle(lib, h)
+
+    @classmethod
+    def from_text(cls, text, threads=0):
+        lib = _capi.load_library()
+        raw = text.encode() if isinstance(text, str) else bytes(text)
+        h = C.c_void_p()
+        if lib.mirt_host_scene_parse(raw, len(raw), threads, C.byref(h)) != 0:
+            raise ValueError(lib.mirt_last_error().decode())
+        return cls._from_host_handle(lib, h)
+
+    def rebuilt(self, threads=0):
+        """Same primitives, Partition tree built again by the library (Partition.cpp:4-14)."""
+        lib = _capi.load_library()
+        d = self.desc()
+        h = C.c_void_p()
+        if lib.mirt_host_scene_from_prims(C.byref(d), self.width, self.height, threads, C.byref(h)) != 0:
+            raise ValueError(lib.mirt_last_error().decode())
+        return self._from_host_handle(lib, h)
+
     # ---- serialisation ------------------------------------------------------------------------------
     def save(self, path):
         np.savez_compressed(path, meta=np.array([self.width, self.height, self.max_depth], dtype=np.int64),

@@ -1,4 +1,4 @@
-"""CPU: the C-ABI library loads and exports every symbol include/mirt.h declares (no compute calls)."""
+"""CPU: the C-ABI library loads and exports every symbol include/*.h declares (no compute calls)."""
 import ctypes as C
 import os
 import re
@@ -9,7 +9,7 @@ from raytracer_amd import _capi
 
 def test_library_exports_every_declared_symbol():
     lib = _capi.load_library()
-    header = open(os.path.join(ROOT, "include", "mirt.h")).read()
+    header = "".join(open(os.path.join(ROOT, "include", h)).read() for h in sorted(os.listdir(os.path.join(ROOT, "include"))) if h.endswith(".h"))
     declared = set(re.findall(r"\b(mirt_[a-z_]+)\s*\(", header))
     bound = {name for name, _, _ in _capi.SYMBOLS}
     assert declared == bound, (declared ^ bound)

@@ -1,0 +1,82 @@
+"""The library's own scene loader and Partition build (include/mirt_host.h) against the reference's.
+
+The expected arrays (tests/golden/*.flat.npz) were flattened from the reference's own Scene / Partition objects
+(scripts/make_golden.py); the inputs are the reference's own scene files (tests/golden/scenes).  Everything that crosses
+the C ABI must be identical bit for bit: boxes, children, leaf contents and order, world-space vertices, sphere
+matrices and their inverses, materials, lights, camera.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from raytracer_amd.scene import FlatScene, _ARRAYS
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SCENES = ["scene1", "scene2", "scene3", "scene4-specular", "scene5", "scene6", "scene7"]
+
+
+def _same(a, b):
+    for name, _, _ in _ARRAYS:
+        x, y = getattr(a, name), getattr(b, name)
+        assert x.shape == y.shape, name
+        assert x.tobytes() == y.tobytes(), name
+    assert a.max_depth == b.max_depth
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_loader_reproduces_the_reference_flattening(name):
+    ref = FlatScene.load(os.path.join(HERE, "golden", name + ".flat.npz"))
+    mine = FlatScene.from_file(os.path.join(HERE, "golden", "scenes", name + ".test"))
+    _same(ref, mine)
+    assert mine.width > 0 and mine.height > 0
+
+
+@pytest.mark.parametrize("name", ["scene5", "scene6", "scene7"])
+def test_tree_build_alone_and_thread_count_do_not_matter(name):
+    ref = FlatScene.load(os.path.join(HERE, "golden", name + ".flat.npz"))
+    for threads in (1, 3, 8):
+        _same(ref, ref.rebuilt(threads=threads))
+
+
+def test_size_output_and_defaults():
+    s = FlatScene.from_text("size 64 48\noutput out.png\ncamera 0 0 5 0 0 0 0 2 0 30\nmaxverts 3\nvertex 0 0 0\nvertex 1 0 0\nvertex 0 1 0\ntri 0 1 2\n")
+    assert (s.width, s.height, s.max_depth, s.output_name) == (64, 48, 5, "out.png")      # Scene.cpp:11
+    assert s.attenuation.tolist() == [1.0, 0.0, 0.0]                                      # Scene.cpp:10
+    assert s.camera[6:9].tolist() == [0.0, 1.0, 0.0]                                      # Camera.cpp:4 normalises up
+    assert s.materials[0].tolist() == [0] * 9 + [np.float32(0.2)] * 3 + [0]               # Scene.cpp:16
+    assert s.n_prims == 1 and s.leaf_prims.tolist() == [0, 0]                             # one triangle ends up in both halves
+
+
+def test_lines_the_reference_skips():
+    base = "size 8 8\ncamera 0 0 5 0 0 0 0 1 0 30\nmaxverts 3\nvertex 0 0 0\nvertex 1 0 0\nvertex 0 1 0\n"
+    a = FlatScene.from_text(base + "tri 0 1 2\n")
+    b = FlatScene.from_text(base + "# comment\n\n   \t\r\nbogus 1 2 3\ndiffuse 1 x 0\nsphere 0 0\npopTransform\ntri 0 1 2")
+    _same(a, b)
+    # '#' only counts in column 0 (Scene.cpp:34); a float may be followed directly by junk, which fails the NEXT read
+    c = FlatScene.from_text(base + " #x\ndiffuse 0.5 0.25 1e-1junk\ntri 0 1 2\n")
+    assert c.materials[0][:3].tolist() == [0.5, 0.25, np.float32(0.1)]
+
+
+def test_transform_stack_matches_manual_composition():
+    txt = ("size 8 8\ncamera 0 0 5 0 0 0 0 1 0 30\nmaxverts 3\nvertex 1 0 0\nvertex 0 1 0\nvertex 0 0 1\n"
+           "pushTransform\ntranslate 1 2 3\nscale 2 2 2\ntri 0 1 2\npopTransform\ntri 0 1 2\n")
+    s = FlatScene.from_text(txt)
+    assert s.tri_verts[0].tolist() == [3, 2, 3, 1, 4, 3, 1, 2, 5]
+    assert s.tri_verts[1].tolist() == [1, 0, 0, 0, 1, 0, 0, 0, 1]
+
+
+@pytest.mark.parametrize("txt, what", [
+    ("size 8 8\ncamera 0 0 5 0 0 0 0 1 0 30\ntri 0 1 2\n", "maxverts"),
+    ("size 8 8\ncamera 0 0 5 0 0 0 0 1 0 30\nmaxverts 2\nvertex 0 0 0\nvertex 1 0 0\ntri 0 1 2\n", "outside"),
+    ("size 8 8\ncamera 0 0 5 0 0 0 0 1 0 30\nmaxverts 1\nvertex 0 0 0\nvertex 1 0 0\n", "more vertices"),
+    ("size 8 8\nmaxverts 1\n", "camera"),
+    ("size 0 8\ncamera 0 0 5 0 0 0 0 1 0 30\n", "size"),
+])
+def test_undefined_behaviour_of_the_reference_is_an_error_here(txt, what):
+    with pytest.raises(ValueError, match=what):
+        FlatScene.from_text(txt)
+
+
+def test_missing_file():
+    with pytest.raises(ValueError, match="Unable to open file"):
+        FlatScene.from_file("/nonexistent/scene.test")
