@@ -42,6 +42,12 @@ int mirt_host_scene_desc(const mirt_host_scene* scene, mirt_scene_desc* desc_out
 /* The `output` command's file name (Scene.cpp:134-139), default "test.png" (Scene.cpp:12). */
 const char* mirt_host_scene_output_name(const mirt_host_scene* scene);
 
+/* Partition::split (Partition.cpp:77-101) recurses for ever on some inputs (a box one float step wide whose only
+ * objects never reach its other half); the reference then overflows its stack.  The library keeps such a node as a
+ * leaf instead and counts it here.  0 means the tree is the reference's tree, node for node; otherwise the reference
+ * cannot load this scene at all and the tree is the reference's down to those leaves. */
+int mirt_host_scene_truncated_nodes(const mirt_host_scene* scene, uint64_t* count);
+
 /* Seconds spent parsing and building the tree (the reference prints neither). */
 int mirt_host_scene_timing(const mirt_host_scene* scene, double* parse_s, double* build_s);
 

@@ -103,6 +103,7 @@ SYMBOLS = [
     ("mirt_host_scene_from_prims", C.c_int, [C.POINTER(SceneDesc), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     ("mirt_host_scene_desc", C.c_int, [C.c_void_p, C.POINTER(SceneDesc), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("mirt_host_scene_output_name", C.c_char_p, [C.c_void_p]),
+    ("mirt_host_scene_truncated_nodes", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("mirt_host_scene_timing", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("mirt_host_scene_destroy", None, [C.c_void_p]),
 ]

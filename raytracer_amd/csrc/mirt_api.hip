@@ -597,6 +597,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	memset(&s->ds, 0, sizeof s->ds);
 	DScene& ds = s->ds;
 	ds.rootRef = REF_NONE;
+	ds.refCull = d->n_spheres == 0 ? 1u : 0u;
 	for (int k = 0; k < 3; ++k) { ds.rootMin[k] = 0.0f; ds.rootMax[k] = -1.0f; }
 	if (d->n_nodes) {
 		const uint32_t r = pk.skipChain(0);

@@ -71,6 +71,7 @@ struct DScene {
 	const uint32_t* leafs;
 	float rootMin[3], rootMax[3];
 	uint32_t rootRef;
+	uint32_t refCull; // 1: triangles only, the walk of the reference tree may skip subtrees beyond the best hit
 	// shading inputs
 	const float4* materials;
 	const float4* lights;

@@ -264,7 +264,16 @@ struct Builder {
 	const Prims& P;
 	std::atomic<int> spare; // worker threads not in use
 	std::atomic<bool> oom;
-	Builder(const Prims& p, int threads) : P(p), spare(threads - 1), oom(false) {}
+	// Partition::split (Partition.cpp:77-101) does not always terminate.  When a box is one float step wide on its longest
+	// axis, "max - (max - min) / 2" rounds to one of its ends, so one child gets the parent's own box (and with it the
+	// parent's own object list), the other a flat one.  If fewer than half of the objects also touch the flat child, that
+	// first child is split again in exactly the same way, for ever: the reference overflows its stack and crashes.  It
+	// happens in practice once a vertex lies exactly on a split plane with its triangles all on the far side (the near
+	// child then holds them by that one point and shrinks around it); the chance grows with |coordinate| / triangle size
+	// and with the triangle count -- a 10 x 10 grid of Stanford dragons has such vertices, one dragon does not.
+	// Here the repeating child is kept as a leaf and counted; everything above it is the reference's tree.
+	std::atomic<uint64_t> truncated;
+	Builder(const Prims& p, int threads) : P(p), spare(threads - 1), oom(false), truncated(0) {}
 
 	int grab(int want) {
 		int got = 0;
@@ -337,6 +346,7 @@ struct Builder {
 			oom.store(true);
 			return;
 		}
+		const size_t nObjs = node->objs.size();
 		std::vector<uint32_t>().swap(node->objs);
 		node->leaf = false;
 		// Partition.cpp:90-97: an empty child next to a non-empty one is deleted; two empty children both stay
@@ -344,6 +354,16 @@ struct Builder {
 		else if (r->objs.empty() && !l->objs.empty()) { delete r; r = nullptr; }
 		node->left = l;
 		node->right = r;
+		// a child with the parent's box repeats the parent's split, matches included: see `truncated`
+		if (((float)matches / (float)nObjs) < 0.5f) {
+			const bool sameL = l && memcmp(&l->box, &node->box, sizeof(Box)) == 0, sameR = r && memcmp(&r->box, &node->box, sizeof(Box)) == 0;
+			if (sameL || sameR) {
+				truncated.fetch_add(1);
+				if (!sameL) split(l, matches);
+				if (!sameR) split(r, matches);
+				return;
+			}
+		}
 		if (l && r && l->objs.size() >= 4096 && r->objs.size() >= 4096 && grab(1) == 1) {
 			std::thread t([this, l, matches]() { split(l, matches); });
 			split(r, matches);
@@ -390,6 +410,7 @@ struct mirt_host_scene {
 	bool haveSize, haveCamera;
 	std::string outputName;
 	double parseSeconds, buildSeconds;
+	uint64_t truncatedNodes;
 };
 
 namespace {
@@ -490,7 +511,7 @@ int build_tree(mirt_host_scene& S, uint32_t threads) {
 		}
 		B.split(root, 0);
 		if (B.oom.load()) rc = mirt_set_error(MIRT_E_NOMEM, "out of host memory while building the Partition tree");
-		else rc = flatten(root, S);
+		else { S.truncatedNodes = B.truncated.load(); rc = flatten(root, S); }
 	} catch (const std::bad_alloc&) {
 		rc = mirt_set_error(MIRT_E_NOMEM, "out of host memory while building the Partition tree");
 	} catch (const std::exception& e) {
@@ -575,6 +596,7 @@ void set_defaults(mirt_host_scene& S) {
 	S.haveSize = S.haveCamera = false;
 	memset(&S.camera, 0, sizeof S.camera);
 	S.parseSeconds = S.buildSeconds = 0.0;
+	S.truncatedNodes = 0;
 }
 
 int parse_text(const char* text, size_t len, mirt_host_scene& S) {
@@ -851,6 +873,12 @@ int mirt_host_scene_desc(const mirt_host_scene* S, mirt_scene_desc* d, uint32_t*
 }
 
 const char* mirt_host_scene_output_name(const mirt_host_scene* S) { return S ? S->outputName.c_str() : ""; }
+
+int mirt_host_scene_truncated_nodes(const mirt_host_scene* S, uint64_t* count) {
+	if (!S || !count) return mirt_set_error(MIRT_E_INVALID, "scene or count is NULL");
+	*count = S->truncatedNodes;
+	return MIRT_OK;
+}
 
 int mirt_host_scene_timing(const mirt_host_scene* S, double* parse_s, double* build_s) {
 	if (!S) return mirt_set_error(MIRT_E_INVALID, "scene is NULL");

@@ -223,16 +223,19 @@ __device__ __forceinline__ float sphere_hit(const RayCtx& r, const float4* __res
 // ---- MODE_REFWALK: walk of the reference's own tree ---------------------------------------------------------------
 // ANY = false: nearest hit under the reference's tie rules.  ANY = true: is there a hit with dist < limit (the shadow
 // query of main.cpp:223-224, where "closest.dist >= length(lightDir)" decides).
-// Children are visited nearer-first and a subtree is skipped when its entry parameter exceeds `tcull`, a bound kept
-// slightly beyond the best distance so far; every candidate at a distance <= best is still visited, so the result
-// equals the reference's exhaustive walk (Partition.cpp:42-52).  Stack in private memory: this mode is the fallback
-// and the cross-check, not the fast path.
+// Children are visited nearer-first and, in scenes made of triangles only, a subtree is skipped when its entry parameter
+// exceeds `tcull`, a bound kept slightly beyond the best distance so far: a point of a triangle lies in a leaf that holds
+// the triangle (Triangle::isInside is an overlap test, Triangle.cpp:58-95), so every candidate at a distance <= best is
+// still visited and the result equals the reference's exhaustive walk (Partition.cpp:42-52).  Sphere::isInside
+// (Sphere.cpp:43-57) gives no such guarantee -- a transformed sphere can be hit outside every leaf that holds it -- so
+// with spheres in the scene (S.refCull == 0) nothing is skipped.  Stack in private memory: this mode is the fallback and
+// the cross-check, not the fast path.
 template <bool ANY>
 __device__ __noinline__ bool traverse_ref(const DScene& S, const RayCtx& r, float limit, Hit& best) {
 	best.dist = __builtin_inff();
 	best.ref = REF_NONE;
 	best.pos = 0xffffffffu;
-	float tcull = ANY ? (limit * r.invLen * 1.0001f + 1e-5f) : __builtin_inff();
+	float tcull = (ANY && S.refCull) ? (limit * r.invLen * 1.0001f + 1e-5f) : __builtin_inff();
 	float tn;
 	if (S.rootRef == REF_NONE || !box_hit<MODE_EXACT>(r, F3(S.rootMin), F3(S.rootMax), tn)) return false; // Partition.cpp:36 on the root
 	uint32_t stkRef[STACK_MAX];
@@ -280,7 +283,7 @@ __device__ __noinline__ bool traverse_ref(const DScene& S, const RayCtx& r, floa
 						best.dist = dist;
 						best.ref = pr;
 						best.pos = pos;
-						tcull = dist * r.invLen * 1.0001f + 1e-5f;
+						if (S.refCull) tcull = dist * r.invLen * 1.0001f + 1e-5f;
 					}
 				}
 			}

@@ -108,6 +108,9 @@ class FlatScene:
             lib.mirt_host_scene_timing(h, C.byref(ps), C.byref(bs))
             fs.parse_seconds, fs.build_seconds = ps.value, bs.value
             fs.output_name = lib.mirt_host_scene_output_name(h).decode()
+            tr = C.c_uint64(0)
+            lib.mirt_host_scene_truncated_nodes(h, C.byref(tr))
+            fs.truncated_nodes = tr.value  # > 0: the reference itself cannot load this scene (its tree build never ends)
             return fs
         finally:
             lib.mirt_host_scene_destroy(h)

@@ -80,3 +80,16 @@ def test_undefined_behaviour_of_the_reference_is_an_error_here(txt, what):
 def test_missing_file():
     with pytest.raises(ValueError, match="Unable to open file"):
         FlatScene.from_file("/nonexistent/scene.test")
+
+
+def test_scene_the_reference_cannot_load_is_truncated_and_counted():
+    """Partition::split (Partition.cpp:77-101) never returns for a 6 x 6 grid of dragons with rotation seed 20251111
+    (one vertex lies exactly on a split plane with its triangles on the far side; the near child shrinks around that
+    point until its box is one float step wide and then repeats itself).  The reference overflows its stack on such a
+    scene -- observed with the 10 x 10 grid of the same seed: its own loader ends in SIGSEGV.  The library keeps the
+    repeating node as a leaf and says how many there were; a grid the reference can load reports none."""
+    from raytracer_amd import workloads
+    small = FlatScene.from_text(workloads.dragon_grid(nx=2, nz=2, seed=20251111))
+    assert small.truncated_nodes == 0 and small.n_prims == 400000
+    big = FlatScene.from_text(workloads.dragon_grid(nx=6, nz=6, seed=20251111))
+    assert big.truncated_nodes == 1 and big.n_prims == 3600000
