@@ -29,11 +29,18 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
 NODE_BYTES, TRI_BYTES, SPHERE_BYTES, RAY_STATE_BYTES = 32, 40, 116, 32
-DRAGON = os.path.join(ROOT, "tests", "golden", "scene7.flat.npz")
-DRAGON_SCENE_FILE = os.path.join(ROOT, "tests", "golden", "scenes", "scene7.test")
+
+# name -> (scene text generator in raytracer_amd.workloads, N=1 size, description).  "dragon" is the configuration the
+# metric is quoted on; the others are the remaining BASELINE configurations, selectable for extra measurements.
+WORKLOADS = {
+    "dragon": ("dragon", (3840, 2160), "final_scenes/scene7 (Stanford Dragon, 100000 triangles, 1 point light) %dx%d maxdepth 5"),
+    "cornell": ("cornell", (640, 480), "final_scenes/scene6 (Cornell box, 34 triangles + 4 spheres, 2 lights) %dx%d maxdepth 5"),
+    "spheres": ("spheres", (1920, 1080), "final_scenes/scene5 + 200 ellipsoids (1200 spheres, 2 lights) %dx%d maxdepth 5"),
+    "grid": ("dragon_grid", (3840, 2160), "10x10 Stanford dragons (10000000 triangles, 16 point lights) %dx%d maxdepth 8"),
+}
 
 
-def cpu_baseline_and_visits(flat, width, height, row_step):
+def cpu_baseline_and_visits(flat, scene_text, width, height, row_step, use_reference):
     """Oracle leg: (cpu_baseline dict, visits[3][3], sample ray counts[3]).  Only the checker is timed here."""
     from oracle.bind import CPort, RefOracle, REF_LIB
     port = CPort(flat)
@@ -43,12 +50,10 @@ def cpu_baseline_and_visits(flat, width, height, row_step):
     rays = [st["primary_rays"], st["shadow_rays"], st["reflection_rays"]]
     sample = "every %dth row of %dx%d (%d rays), 1 thread" % (row_step, width, height, sum(rays))
     base = {"value": sum(rays) / t_port / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port", "sample": sample + ", C restatement with visit counters on"}
-    if os.path.exists(REF_LIB) and os.path.exists(DRAGON_SCENE_FILE):
+    if use_reference and os.path.exists(REF_LIB):
         import tempfile
-        lines = open(DRAGON_SCENE_FILE).read().split("\n")
-        lines = ["size %d %d" % (width, height) if ln.strip().startswith("size ") else ln for ln in lines]
-        with tempfile.NamedTemporaryFile("w", suffix=".test", delete=False) as f:
-            f.write("\n".join(lines))
+        with tempfile.NamedTemporaryFile("wb", suffix=".test", delete=False) as f:
+            f.write(scene_text)
         try:
             ref = RefOracle(f.name)  # the reference's own parser + Partition build
             _, rs = ref.render(width, height, row_step=row_step)
@@ -73,11 +78,12 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo = rehearsal with ranks sharing a GPU)")
     ap.add_argument("--pipeline", type=int, default=0, help="frames in flight (each on its own HIP stream and workspace)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-row-step", type=int, default=16)
+    ap.add_argument("--cpu-row-step", type=int, default=0, help="CPU baseline sample: every n-th row (0 = 16, or 128 for the grid)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="dragon")
     args = ap.parse_args()
 
     import torch
-    from raytracer_amd import _capi, multigpu
+    from raytracer_amd import _capi, multigpu, workloads
     from raytracer_amd.device import DeviceScene
     from raytracer_amd.scene import FlatScene
 
@@ -96,10 +102,13 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
-    width = args.width or (3840 if world == 1 else 7680)
-    height = args.height or (2160 if world == 1 else 4320)
+    gen, (w1, h1), describe = WORKLOADS[args.workload]
+    width = args.width or (w1 if world == 1 else 2 * w1)   # N > 1: the 8K frame of the Dragon, cut over the ranks
+    height = args.height or (h1 if world == 1 else 2 * h1)
     trace_mode = _capi.TRACE_FAST if args.trace_mode == "fast" else _capi.TRACE_EXACT
-    flat = FlatScene.load(DRAGON).with_size(width, height)
+    # scene text -> the library's own parser and Partition build (mirt_host_scene_parse) -> flattened scene
+    scene_text = getattr(workloads, gen)(width, height)
+    flat = FlatScene.from_text(scene_text)
     scene = DeviceScene(flat, dev_index)
     params = multigpu.rank_params(width, height, rank, world, trace_mode=trace_mode)
     nbytes = multigpu.per_rank_bytes(width, height, world) if world > 1 else width * height * 3
@@ -174,15 +183,15 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rays * args.steps / elapsed / 1e6
         out = {
-            "metric": "Mrays/s (primary+shadow+reflection), Dragon %dx%d maxdepth 5" % (width, height),
+            "metric": "Mrays/s (primary+shadow+reflection), %s %dx%d maxdepth %d" % (args.workload.capitalize(), width, height, flat.max_depth),
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "final_scenes/scene7 (Stanford Dragon, 100000 triangles, 1 point light) %dx%d maxdepth 5 diffuse+specular+shadows+reflections" % (width, height),
+                "workload": (describe % (width, height)) + " diffuse+specular+shadows+reflections",
                 "trace_mode": args.trace_mode, "frames_in_flight": depth,
                 "parallelism": "single GPU, whole image" if world == 1 else "interleaved %dx%d tiles over %d GPUs, scene replicated, %s gather of packed tiles to rank 0" % (multigpu.TILE_W, multigpu.TILE_H, world, "RCCL" if not gloo else "gloo (rehearsal)"),
-                "scene_source": "flattened by the reference's own parser and Partition build (tests/golden/scene7.flat.npz)",
+                "scene_source": "scene text parsed and Partition tree built by the library's host loader in %.2f s (%d nodes, %d leaf entries)" % (flat.parse_seconds + flat.build_seconds, flat.nodes.shape[0], flat.leaf_prims.shape[0]),
             },
             "rays_per_frame": {"primary": int(rays[0]), "shadow": int(rays[1]), "reflection": int(rays[2])},
             "kernels": kern,
@@ -191,20 +200,22 @@ def main():
         frame_ms = sum(k["ms_per_frame"] for k in kern.values())
         out["device_ms_per_frame"] = frame_ms
         if world == 1 and not args.no_cpu_baseline:
-            base, vis, srays = cpu_baseline_and_visits(flat, width, height, args.cpu_row_step)
+            row_step = args.cpu_row_step or (128 if args.workload == "grid" else 16)
+            # the reference needs minutes to load the 10 M triangle grid: that workload is timed on the C restatement
+            base, vis, srays = cpu_baseline_and_visits(flat, scene_text, width, height, row_step, use_reference=args.workload != "grid")
             out["cpu_baseline"] = base
             # algorithmic bytes per ray kind from the exhaustive walk's visit counts on the sample
             per_ray = []
             for k in range(3):
                 n = max(int(srays[k]), 1)
-                per_ray.append((float(vis[k][0]) * NODE_BYTES + float(vis[k][2]) * TRI_BYTES) / n + RAY_STATE_BYTES)
+                per_ray.append((float(vis[k][0]) * NODE_BYTES + float(vis[k][2]) * (TRI_BYTES if flat.tri_verts.shape[0] >= flat.spheres.shape[0] else SPHERE_BYTES)) / n + RAY_STATE_BYTES)
             frame_bytes = float(rays[0]) * per_ray[0] + float(rays[1]) * per_ray[1] + float(rays[2]) * per_ray[2] + width * height * 3
             # dominant kernels: everything that walks the tree (primary + trace + shade); resolve is the remainder
             walk_ms = sum(kern[k]["ms_per_frame"] for k in ("primary", "trace", "shade") if k in kern)
             achieved = frame_bytes / (walk_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "r01", "hbm_traffic.json")
-            if os.path.exists(tpath):  # PMC counters cannot be read from inside this process; separate rocprofv3 --pmc passes
+            if args.workload == "dragon" and (width, height) == (3840, 2160) and os.path.exists(tpath):  # PMC counters cannot be read from inside this process; separate rocprofv3 --pmc passes
                 traffic = json.load(open(tpath))["hbm_bytes_per_frame"]
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
