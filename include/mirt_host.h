@@ -53,6 +53,12 @@ int mirt_host_scene_timing(const mirt_host_scene* scene, double* parse_s, double
 
 void mirt_host_scene_destroy(mirt_host_scene* scene);
 
+/* Replaces Renderer::createImage(BYTE* pixels, std::string outputFileName) (Renderer.h:9, Renderer.cpp:12-15): writes
+ * the B,G,R buffer that mirt_render filled (top row first) as an 8-bit RGB PNG.  The file decodes to the pixels
+ * FreeImage's would; its bytes differ (deflate settings).  Rows are compressed in stripes on `threads` CPU threads
+ * (0 = number of CPUs, at most 16). */
+int mirt_write_png(const char* path, const uint8_t* bgr, uint32_t width, uint32_t height, uint32_t threads);
+
 #ifdef __cplusplus
 }
 #endif

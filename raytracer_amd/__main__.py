@@ -1,0 +1,78 @@
+"""Scene file in, PNG and report out: what the reference's createRender does for one scene (main.cpp:104-173), on the GPU.
+
+    python -m raytracer_amd scene.test [--out image.png] [--size W H] [--features 15] [--debug 6] [--device 0]
+
+The output name defaults to the scene's `output` command, as in the reference (main.cpp:113-119).  The report lists the
+same facts as createPerformanceReport (main.cpp:314-344), with the object and light counters filled in (the reference
+prints uninitialised ones, Scene.h:47) and device times instead of whole seconds.
+"""
+import argparse
+import os
+import time
+
+from . import _capi
+from .device import DeviceScene
+from .png import write_png
+from .scene import FlatScene
+
+FEATURE_NAMES = [(1, "DIFFUSE"), (2, "SPECULAR"), (4, "SHADOWS"), (8, "REFLECTIONS")]            # main.cpp:35-49
+DEBUG_NAMES = ["DIFFUSE_INTENSITY", "SPECULAR_INTENSITY", "NORMAL_MAP", "SHADOW_MAP", "PRIMARY_INTERSECTION_MAP",
+               "LIGHT_DIRECTION_MAP", "NONE"]                                                     # main.cpp:24-33
+
+
+def render_file(scene_path, out_path=None, size=None, features=_capi.F_ALL, debug=_capi.DEBUG_NONE, device=0, report=True):
+    t0 = time.perf_counter()
+    flat = FlatScene.from_file(scene_path)
+    t_load = time.perf_counter() - t0
+    if size:
+        flat = flat.with_size(*size)
+    out_path = out_path or flat.output_name
+    t0 = time.perf_counter()
+    with DeviceScene(flat, device) as s:
+        t_upload = time.perf_counter() - t0
+        img, st = s.render(flat.width, flat.height, features=features, debug=debug)
+    t0 = time.perf_counter()
+    write_png(out_path, img)
+    t_png = time.perf_counter() - t0
+    lines = []
+    if report:
+        n_px = flat.width * flat.height
+        rays = st["primary_rays"] + st["shadow_rays"] + st["reflection_rays"]
+        point = int((flat.lights[:, 3] > 0).sum())
+        lines = [
+            "PERFORMANCE REPORT FOR " + os.path.basename(out_path),
+            "--------------------------------------------------------------------", "",
+            "100% Completed", "",
+            "Input Scene File: %s" % scene_path, "Output Image: %s" % out_path,
+            "Resolution: %dx%d" % (flat.width, flat.height), "Pixels Processed: %d" % n_px, "",
+            "Features Enabled: " + " ".join(n for b, n in FEATURE_NAMES if features & b),
+            "Debug Options: " + DEBUG_NAMES[debug], "",
+            "Render Time: %.3f ms on the device" % st["device_ms"],
+            "Milliseconds Per Pixel: %.3g" % (st["device_ms"] / n_px), "",
+            "Time Breakdown",
+            "Scene load + tree build: %.3f s, upload: %.3f s, PNG: %.3f s" % (t_load, t_upload, t_png),
+            "Rays: %d primary, %d shadow, %d reflection (%.1f Mrays/s)" % (st["primary_rays"], st["shadow_rays"], st["reflection_rays"], rays / max(st["device_ms"], 1e-9) / 1e3),
+            "Total objects: %d" % flat.n_prims, "----- Spheres: %d" % flat.spheres.shape[0], "----- Triangles: %d" % flat.tri_verts.shape[0],
+            "Total lights: %d" % flat.lights.shape[0], "----- Directional: %d" % (flat.lights.shape[0] - point), "----- Point: %d" % point,
+        ]
+        os.makedirs("reports", exist_ok=True)                                                    # main.cpp:22
+        with open(os.path.join("reports", os.path.basename(out_path) + "_report.txt"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+    return img, st, lines
+
+
+def main():
+    ap = argparse.ArgumentParser(prog="python -m raytracer_amd")
+    ap.add_argument("scene")
+    ap.add_argument("--out")
+    ap.add_argument("--size", type=int, nargs=2, metavar=("W", "H"))
+    ap.add_argument("--features", type=int, default=_capi.F_ALL)
+    ap.add_argument("--debug", type=int, default=_capi.DEBUG_NONE)
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args()
+    _, _, lines = render_file(a.scene, a.out, a.size, a.features, a.debug, a.device)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()

@@ -106,6 +106,7 @@ SYMBOLS = [
     ("mirt_host_scene_truncated_nodes", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("mirt_host_scene_timing", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("mirt_host_scene_destroy", None, [C.c_void_p]),
+    ("mirt_write_png", C.c_int, [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
 ]
 
 _lib = None

@@ -89,3 +89,18 @@ def test_c5_ten_million_triangles_sixteen_lights(goldens):
         img, st = s.render(3840, 2160)
         assert np.array_equal(img[g["rows_4k"]], g["bgr_rows_4k"])
         assert st["primary_rays"] == 3840 * 2160 and st["shadow_rays"] == 16 * (st["shadow_rays"] // 16)
+
+
+def test_scene_file_to_png_end_to_end(tmp_path, goldens, monkeypatch):
+    """python -m raytracer_amd: the whole of createRender (main.cpp:104-173) -- load, render, save, report."""
+    import os
+    from PIL import Image
+    from raytracer_amd.__main__ import render_file
+    monkeypatch.chdir(tmp_path)
+    scene = os.path.join(os.path.dirname(__file__), "golden", "scenes", "scene6.test")
+    img, st, lines = render_file(scene, out_path=str(tmp_path / "cornell.png"))
+    g = goldens("c1_cornell")
+    assert np.array_equal(img, g["bgr"])
+    assert np.array_equal(np.array(Image.open(tmp_path / "cornell.png")), g["bgr"][..., ::-1])
+    assert "Resolution: 640x480" in lines and "----- Spheres: 4" in lines and "----- Triangles: 34" in lines
+    assert (tmp_path / "reports" / "cornell.png_report.txt").exists()
