@@ -114,6 +114,7 @@ struct mirt_scene {
 	uint32_t nLights = 0;
 	int32_t maxDepth = 0;
 	uint32_t wideDepth = 0;
+	uint32_t diag[8] = {0}; // builder facts: binary interior nodes, binary leaves, wide nodes with 1..4 children
 	std::vector<FrameCtx*> ctxs; // one per stream that has rendered with this scene
 	bool profiling = false;
 };
@@ -535,34 +536,87 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	for (uint32_t i = 0; i < d->n_spheres; ++i) if (sphNew[i] == 0xffffffffu) { sphNew[i] = (uint32_t)sphOld.size(); sphOld.push_back(i); }
 	if (triOld.size() > BVH_FIRST_MASK || sphOld.size() > BVH_FIRST_MASK) return fail(MIRT_E_INVALID, "more than %u primitives of one kind", BVH_FIRST_MASK);
 
-	// wide nodes of the hierarchy
-	std::vector<float> bvhWide;
-	uint32_t bvhRoot = BVH_DONE;
+	// 4-wide nodes with quantised child boxes (layout in mirt_device.h)
+	std::vector<uint32_t> bvhWide;
+	uint32_t bvhRoot = BVH_DONE, bvhWideDepth = 0;
+	uint32_t bvhDiag[8] = {0};
 	float bvhMin[3] = {0, 0, 0}, bvhMax[3] = {-1, -1, -1};
 	if (!bb.nodes.empty()) {
 		struct Emit {
 			const BvhBuilder& bb;
 			const std::vector<uint32_t>& kindIndex;
-			std::vector<float>& out;
+			std::vector<uint32_t>& out;
+			uint32_t maxDepth;
+			uint32_t* diag;
 			uint32_t leafRef(const BvhNode& n) const {
 				return BVH_LEAF | (n.kind ? BVH_SPHERES : 0u) | ((n.count - 1) << BVH_COUNT_SHIFT) | kindIndex[n.first];
 			}
-			uint32_t ref(int32_t i) { return bb.nodes[i].left < 0 ? leafRef(bb.nodes[i]) : emit(i); }
-			uint32_t emit(int32_t i) {
+			uint32_t emit(int32_t i, uint32_t depth) {
+				if (depth > maxDepth) maxDepth = depth;
 				const uint32_t me = (uint32_t)(out.size() / 16);
-				out.resize(out.size() + 16, 0.0f);
-				const BvhNode n = bb.nodes[i];
-				const BvhNode &l = bb.nodes[n.left], &r = bb.nodes[n.right];
-				const uint32_t lr = ref(n.left), rr = ref(n.right);
-				float* w = out.data() + (size_t)me * 16;
-				memcpy(w + 0, l.lo, 12); memcpy(w + 3, &lr, 4);
-				memcpy(w + 4, l.hi, 12); memcpy(w + 7, &rr, 4);
-				memcpy(w + 8, r.lo, 12);
-				memcpy(w + 12, r.hi, 12);
+				out.resize(out.size() + 16, 0u);
+				// up to four children: open the interior child with the largest surface area until none is left or there are four
+				int32_t ch[4] = { bb.nodes[i].left, bb.nodes[i].right, -1, -1 };
+				int n = 2;
+				while (n < 4) {
+					int best = -1;
+					float bestArea = -1.0f;
+					for (int k = 0; k < n; ++k) {
+						const BvhNode& c = bb.nodes[ch[k]];
+						if (c.left < 0) continue;
+						const float a = BvhBuilder::area(c.lo, c.hi);
+						if (a > bestArea) { bestArea = a; best = k; }
+					}
+					if (best < 0) break;
+					const BvhNode c = bb.nodes[ch[best]];
+					ch[best] = c.left;
+					ch[n++] = c.right;
+				}
+				const BvhNode& nd = bb.nodes[i];
+				uint32_t w[16] = {0};
+				uint32_t ex[3];
+				float scale[3];
+				for (int k = 0; k < 3; ++k) {
+					const double ext = (double)nd.hi[k] - (double)nd.lo[k];
+					int e = 0;
+					(void)frexp(ext / 255.0, &e); // ext/255 = m * 2^e, m in [0.5, 1): 2^e >= ext/255
+					int biased = e + 127;
+					if (!(ext > 0.0)) biased = 1;
+					if (biased < 1) biased = 1;
+					if (biased > 200) biased = 200;
+					ex[k] = (uint32_t)biased;
+					scale[k] = ldexpf(1.0f, biased - 127);
+					memcpy(&w[k], &nd.lo[k], 4);
+				}
+				w[3] = ex[0] | (ex[1] << 8) | (ex[2] << 16);
+				uint32_t refs[4] = { BVH_DONE, BVH_DONE, BVH_DONE, BVH_DONE };
+				for (int c = 0; c < 4; ++c) {
+					uint32_t qlo[3] = {255, 255, 255}, qhi[3] = {0, 0, 0};
+					if (c < n) {
+						const BvhNode& cn = bb.nodes[ch[c]];
+						for (int k = 0; k < 3; ++k) {
+							double a = floor(((double)cn.lo[k] - (double)nd.lo[k]) / (double)scale[k]);
+							double b = ceil(((double)cn.hi[k] - (double)nd.lo[k]) / (double)scale[k]);
+							if (a < 0.0) a = 0.0;
+							if (b > 255.0) b = 255.0; // cannot happen: 255 * scale >= the node's extent
+							if (b < a) b = a;
+							qlo[k] = (uint32_t)a;
+							qhi[k] = (uint32_t)b;
+						}
+					}
+					w[4] |= qlo[0] << (8 * c); w[5] |= qlo[1] << (8 * c); w[6] |= qlo[2] << (8 * c);
+					w[7] |= qhi[0] << (8 * c); w[8] |= qhi[1] << (8 * c); w[9] |= qhi[2] << (8 * c);
+				}
+				diag[1 + n]++;
+				memcpy(out.data() + (size_t)me * 16, w, sizeof w);
+				for (int c = 0; c < n; ++c) refs[c] = bb.nodes[ch[c]].left < 0 ? leafRef(bb.nodes[ch[c]]) : emit(ch[c], depth + 1);
+				memcpy(out.data() + (size_t)me * 16 + 10, refs, sizeof refs);
 				return me;
 			}
-		} em = {bb, kindIndex, bvhWide};
-		bvhRoot = em.ref(0);
+		} em = {bb, kindIndex, bvhWide, 0, bvhDiag};
+		for (const BvhNode& bn : bb.nodes) bvhDiag[bn.left < 0 ? 1 : 0]++;
+		bvhRoot = bb.nodes[0].left < 0 ? em.leafRef(bb.nodes[0]) : em.emit(0, 1);
+		bvhWideDepth = em.maxDepth;
 		memcpy(bvhMin, bb.nodes[0].lo, 12);
 		memcpy(bvhMax, bb.nodes[0].hi, 12);
 	}
@@ -610,7 +664,8 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		}
 	}
 	s->wideDepth = pk.maxDepth;
-	s->bvhDepth = bb.maxDepth;
+	s->bvhDepth = bvhWideDepth;
+	memcpy(s->diag, bvhDiag, sizeof bvhDiag);
 	ds.bvhRoot = bvhRoot;
 	memcpy(ds.bvhMin, bvhMin, 12);
 	memcpy(ds.bvhMax, bvhMax, 12);
@@ -704,9 +759,11 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	ds.dbg = (unsigned long long*)s->dbg.p;
 	ds.ovf = nullptr;
 	ds.ovfStride = (uint32_t)s->numCUs * GRID_BLOCKS_PER_CU * BLOCK;
-	s->deepBvh = bb.maxDepth + 1 > STACK_LDS;
+	// a step pushes up to three siblings, so a walk can hold 3 entries per level
+	const uint32_t stackNeed = 3u * bvhWideDepth + 1u;
+	s->deepBvh = stackNeed > STACK_LDS;
 	if (!e && s->deepBvh) {
-		e = s->ovf.ensure((size_t)(bb.maxDepth + 1 - STACK_LDS) * ds.ovfStride * 4);
+		e = s->ovf.ensure((size_t)(stackNeed - STACK_LDS) * ds.ovfStride * 4);
 		ds.ovf = (uint32_t*)s->ovf.p;
 	}
 	if (!e && hipStreamCreate(&s->stream) != hipSuccess) e = fail(MIRT_E_DEVICE, "hipStreamCreate failed");
@@ -776,6 +833,7 @@ int mirt_scene_query(mirt_scene* s, uint32_t what, uint64_t* v) {
 		break;
 	case MIRT_Q_TREE_WIDE_DEPTH: *v = s->wideDepth; break;
 	default:
+		if (what >= 120 && what < 128) { *v = s->diag[what - 120]; break; }
 		if (what >= 100 && what < 116) { // diagnostic event counters of MIRT_STATS builds (read and clear)
 			unsigned long long x = 0;
 			HIPCHK(hipSetDevice(s->device));

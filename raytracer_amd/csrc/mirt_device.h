@@ -3,11 +3,14 @@
 // mirt_scene_create re-packs the flattened scene into two structures:
 //
 // (1) The primitive hierarchy ("bvh"): a binned-SAH BVH over the primitives, each primitive once, built on the host
-//     (mirt_bvh.h).  It is a conservative FILTER: it only decides which primitives are tested at all.
-//       wide node, 64 B = 4 x float4, fetched by one lane as 4 dwordx4 loads of one 64-B sector pair:
-//           q0 = { left.lo.xyz,  left_ref  }   q1 = { left.hi.xyz,  right_ref }
-//           q2 = { right.lo.xyz, 0 }           q3 = { right.hi.xyz, 0 }
-//       ref: BVH_DONE | interior node index | BVH_LEAF [| BVH_SPHERES] | (count-1) << 27 | first
+//     (mirt_bvh.h) and collapsed to four children per node.  It is a conservative FILTER: it only decides which
+//     primitives are tested at all.  The tracing kernels are limited by the number of 16-byte loads a lane issues
+//     (the L1 data path serves about one diverging lane per cycle), so a node is 64 B for FOUR child boxes:
+//       q0 = { origin.xyz (float), ex | ey << 8 | ez << 16 }     scale_k = 2^(e_k - 127)
+//       q1 = { lo.x[4], lo.y[4], lo.z[4], hi.x[4] }              one byte per child: bound = origin_k + byte * scale_k,
+//       q2 = { hi.y[4], hi.z[4], ref0, ref1 }                    lower bounds rounded down, upper bounds rounded up
+//       q3 = { ref2, ref3, 0, 0 }
+//       ref: BVH_DONE (empty slot) | interior node index | BVH_LEAF [| BVH_SPHERES] | (count-1) << 27 | first
 //       A leaf names `count` (1..8) consecutive records of the triangle or sphere array: no indirection.
 //     Triangles and spheres are stored in hierarchy order.
 //

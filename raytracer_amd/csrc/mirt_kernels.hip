@@ -383,55 +383,75 @@ struct Walker {
 		return cur != BVH_DONE;
 	}
 
-	// One round: descend to the next leaf, test its primitives, pop.  Returns false when the walk is over.
-	__device__ __forceinline__ bool advance(const DScene& S, LdsStack<OVF>& stk) {
-		STAT_WAVE(S, 6); // advance rounds (wave)
-		STAT_LANE(S, 7); // advance rounds (lanes)
-		while (!(cur & BVH_LEAF)) {
-			STAT_WAVE(S, 0); // node steps (wave iterations)
-			STAT_LANE(S, 1); // node steps (lanes)
-			const float4* nd = S.bvh + (size_t)cur * 4;
-			const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-			const uint32_t lref = __float_as_uint(q0.w), rref = __float_as_uint(q1.w);
-			float tl, tr;
-			const bool hl = box_filter(r, q0, q1, tcull, tl);
-			const bool hr = box_filter(r, q2, q3, tcull, tr);
-			if (hl && hr) {
-				const bool leftFirst = tl <= tr;
-				stk.push(sp, leftFirst ? rref : lref);
-				++sp;
-				cur = leftFirst ? lref : rref;
-			}
-			else if (hl) cur = lref;
-			else if (hr) cur = rref;
-			else if (sp > 0) cur = stk.pop(--sp);
-			else cur = BVH_DONE;
+	__device__ __forceinline__ bool at_node() const { return !(cur & BVH_LEAF); }
+
+	// One interior node of the 4-wide hierarchy (layout in mirt_device.h): decode the four children's quantised boxes
+	// straight into slab parameters (t = q * (scale/d) + (origin - o)/d, one FMA per plane), go to the nearest hit child
+	// and push the other hit children, farthest first; none hit: pop.  Call only while at_node().
+	// The quantised boxes contain the padded primitive bounds (lower bounds rounded down, upper bounds up), so the filter
+	// stays conservative; see box_filter for the rounding argument.
+	__device__ __forceinline__ void node_step(const DScene& S, LdsStack<OVF>& stk) {
+		STAT_WAVE(S, 0); // node steps (wave iterations)
+		STAT_LANE(S, 1); // node steps (lanes)
+		const uint4* nd = (const uint4*)S.bvh + (size_t)cur * 4;
+		const uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+		const float ax = __uint_as_float((q0.w & 0xffu) << 23) * r.ie.x;
+		const float ay = __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * r.ie.y;
+		const float az = __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * r.ie.z;
+		const float bx = __builtin_fmaf(__uint_as_float(q0.x), r.ie.x, -r.oie.x);
+		const float by = __builtin_fmaf(__uint_as_float(q0.y), r.ie.y, -r.oie.y);
+		const float bz = __builtin_fmaf(__uint_as_float(q0.z), r.ie.z, -r.oie.z);
+		uint32_t key[4], ref[4];
+		ref[0] = q2.z; ref[1] = q2.w; ref[2] = q3.x; ref[3] = q3.y;
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			const int sh = 8 * c;
+			const float t1 = __builtin_fmaf((float)((q1.x >> sh) & 0xffu), ax, bx), t2 = __builtin_fmaf((float)((q1.w >> sh) & 0xffu), ax, bx);
+			const float t3 = __builtin_fmaf((float)((q1.y >> sh) & 0xffu), ay, by), t4 = __builtin_fmaf((float)((q2.x >> sh) & 0xffu), ay, by);
+			const float t5 = __builtin_fmaf((float)((q1.z >> sh) & 0xffu), az, bz), t6 = __builtin_fmaf((float)((q2.y >> sh) & 0xffu), az, bz);
+			const float tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+			const float tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+			const bool hit = (tmin <= tmax) && (tmax >= 0.0f) && !(tmin > tcull) && ref[c] != BVH_DONE;
+			// non-negative floats order like their bit patterns
+			key[c] = hit ? __float_as_uint(fmaxf(tmin, 0.0f)) : 0xffffffffu;
 		}
-		if (cur == BVH_DONE) return false;
-		// leaf: 1..8 consecutive records of one kind
-		const uint32_t first = cur & BVH_FIRST_MASK;
-		const uint32_t cnt = ((cur >> BVH_COUNT_SHIFT) & 7u) + 1u;
+#define MIRT_CSWAP(i, j) { const bool sw = key[j] < key[i]; const uint32_t ki = key[i], ri = ref[i]; \
+		key[i] = sw ? key[j] : ki; ref[i] = sw ? ref[j] : ri; key[j] = sw ? ki : key[j]; ref[j] = sw ? ri : ref[j]; }
+		MIRT_CSWAP(0, 1) MIRT_CSWAP(2, 3) MIRT_CSWAP(0, 2) MIRT_CSWAP(1, 3) MIRT_CSWAP(1, 2)
+#undef MIRT_CSWAP
+		if (key[0] == 0xffffffffu) {
+			cur = sp > 0 ? stk.pop(--sp) : BVH_DONE;
+			return;
+		}
+		cur = ref[0];
+		if (key[3] != 0xffffffffu) { stk.push(sp, ref[3]); ++sp; }
+		if (key[2] != 0xffffffffu) { stk.push(sp, ref[2]); ++sp; }
+		if (key[1] != 0xffffffffu) { stk.push(sp, ref[1]); ++sp; }
+	}
+
+	// One primitive of the current leaf (1..8 consecutive records of one kind).  Call only while cur is a leaf.
+	// Afterwards cur is the rest of the leaf, or the next stack entry, or BVH_DONE.  Returns true while the same leaf goes on.
+	__device__ __forceinline__ bool leaf_step(const DScene& S, LdsStack<OVF>& stk) {
+		STAT_WAVE(S, 2); // primitive tests (wave iterations)
+		STAT_LANE(S, 3); // primitive tests (lanes)
+		const uint32_t idx = cur & BVH_FIRST_MASK;
 		const bool sph = (cur & BVH_SPHERES) != 0;
+		const bool more = ((cur >> BVH_COUNT_SHIFT) & 7u) != 0u;
 		const bool any = limit >= 0.0f;
-		for (uint32_t k = 0; k < cnt; ++k) {
-			STAT_WAVE(S, 2); // primitive tests (wave iterations)
-			STAT_LANE(S, 3); // primitive tests (lanes)
-			const uint32_t idx = first + k;
-			float dist;
-			if (sph) {
-				f3 dummy;
-				dist = sphere_hit<false>(r, S.spheres + (size_t)idx * SPHERE_F4, dummy);
-			}
-			else {
-				dist = tri_hit<MODE>(r, S.tris + (size_t)idx * 4, tcull);
-			}
-			if (!(dist >= 0.0f) || isinf(dist)) continue;
+		float dist;
+		if (sph) {
+			f3 dummy;
+			dist = sphere_hit<false>(r, S.spheres + (size_t)idx * SPHERE_F4, dummy);
+		}
+		else {
+			dist = tri_hit<MODE>(r, S.tris + (size_t)idx * 4, tcull);
+		}
+		if (dist >= 0.0f && !isinf(dist)) {
 			const uint32_t ref = sph ? (PRIM_SPHERE | idx) : idx;
 			const bool tie = !any && dist == best.dist && ref != best.ref;
-			const bool cand = any ? (dist < limit) : (dist < best.dist || tie);
-			if (!cand) continue;
+			bool cand = any ? (dist < limit) : (dist < best.dist || tie);
 			uint32_t pos = 0;
-			if (MODE == MODE_EXACT) {
+			if (cand && MODE == MODE_EXACT) {
 				if (!strict) {
 					if (tie) { needStrict = true; cur = BVH_DONE; return false; }
 				}
@@ -440,27 +460,42 @@ struct Walker {
 					STAT_LANE(S, 5); // membership checks (lanes)
 					const uint4 info = sph ? S.sphInfo[idx] : S.triInfo[idx];
 					pos = membership(S, r, info.z, info.w);
-					if (pos == REF_NONE) continue; // the reference's tree never reaches this primitive along this ray
+					if (pos == REF_NONE) cand = false; // the reference's tree never reaches this primitive along this ray
 				}
 			}
-			if (any) {
-				best.dist = dist;
-				best.ref = ref;
-				best.pos = pos;
-				cur = BVH_DONE;
-				return false;
-			}
-			// Partition.h:33 (first in a leaf wins), Partition.cpp:47 (left subtree wins) == lower visiting rank wins
-			if (dist < best.dist || pos < best.pos) {
-				best.dist = dist;
-				best.ref = ref;
-				best.pos = pos;
-				tcull = dist * r.invLen * 1.0001f + 1e-5f;
+			if (cand) {
+				if (any) {
+					best.dist = dist;
+					best.ref = ref;
+					best.pos = pos;
+					cur = BVH_DONE;
+					return false;
+				}
+				// Partition.h:33 (first in a leaf wins), Partition.cpp:47 (left subtree wins) == lower visiting rank wins
+				if (dist < best.dist || pos < best.pos) {
+					best.dist = dist;
+					best.ref = ref;
+					best.pos = pos;
+					tcull = dist * r.invLen * 1.0001f + 1e-5f;
+				}
 			}
 		}
-		if (sp == 0) { cur = BVH_DONE; return false; }
-		cur = stk.pop(--sp);
-		return true;
+		if (more) {
+			cur = cur - (1u << BVH_COUNT_SHIFT) + 1u; // one record fewer, starting one further
+			return true;
+		}
+		cur = sp > 0 ? stk.pop(--sp) : BVH_DONE;
+		return false;
+	}
+
+	// One round: descend to the next leaf, test its primitives, pop.  Returns false when the walk is over.
+	__device__ __forceinline__ bool advance(const DScene& S, LdsStack<OVF>& stk) {
+		STAT_WAVE(S, 6); // advance rounds (wave)
+		STAT_LANE(S, 7); // advance rounds (lanes)
+		while (at_node()) node_step(S, stk);
+		if (cur == BVH_DONE) return false;
+		while (leaf_step(S, stk)) {}
+		return cur != BVH_DONE;
 	}
 
 	// After a deferred walk has ended: is its answer final?  false = walk the ray again with start(..., strict = true).
@@ -581,6 +616,13 @@ struct Supply {
 	}
 };
 
+#ifndef MIRT_SCHED
+#define MIRT_SCHED 1
+#endif
+#ifndef MIRT_NODE_WEIGHT
+#define MIRT_NODE_WEIGHT 1
+#define MIRT_LEAF_WEIGHT 1
+#endif
 #ifndef MIRT_REFILL_MIN
 #define MIRT_REFILL_MIN 20
 #endif
@@ -624,7 +666,8 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DScene S, DFrame F, uint8_t* __
 	uint32_t tag = 0;
 	uint32_t nShadowTraced = 0;
 	for (;;) {
-		if (__popcll(__ballot(!alive)) >= MIRT_REFILL_MIN || sup.exhausted()) {
+		const int nDead = __popcll(__ballot(!alive));
+		if (sup.exhausted() ? (nDead == 64 || __ballot(parked) != 0ull) : nDead >= MIRT_REFILL_MIN) {
 			// (0) parked lanes make their answer final; the rare ray that fails the check is walked again, strictly
 			if (MODE == MODE_EXACT && parked && !w.verify(S)) {
 				alive = w.start(S, w.r.o, w.r.d, w.limit, true);
@@ -729,10 +772,28 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DScene S, DFrame F, uint8_t* __
 			}
 			if (got == 0 && __ballot(alive || parked) == 0ull) break;
 		}
+#if MIRT_SCHED
+		// One step per iteration for the whole wave: either every lane that stands at an interior node takes a node step, or
+		// every lane that stands at a leaf tests one primitive -- whichever group is larger.
+		if (MODE != MODE_REFWALK) {
+			const bool wantNode = alive && w.at_node();
+			const bool wantLeaf = alive && !wantNode;
+			const int nNode = __popcll(__ballot(wantNode)), nLeaf = __popcll(__ballot(wantLeaf));
+			if (nNode * MIRT_NODE_WEIGHT >= nLeaf * MIRT_LEAF_WEIGHT) {
+				if (wantNode) w.node_step(S, stk);
+			}
+			else if (wantLeaf) w.leaf_step(S, stk);
+			if (alive && w.cur == BVH_DONE) {
+				alive = false;
+				parked = true;
+			}
+		}
+#else
 		if (MODE != MODE_REFWALK && alive) {
 			alive = w.advance(S, stk);
 			parked = !alive;
 		}
+#endif
 	}
 	if (nbuf) flush_list(myList, nbuf, nextList, F.counters + CTR_NHITS(depth));
 	// statistics: one atomic per wave
