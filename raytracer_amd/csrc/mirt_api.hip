@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -114,6 +115,7 @@ struct mirt_scene {
 	uint32_t nLights = 0;
 	int32_t maxDepth = 0;
 	uint32_t wideDepth = 0;
+	uint32_t refillMin = 64; // < 64: finished lanes of a wave are refilled once this many are idle (k_trace<REFILL>)
 	uint32_t diag[8] = {0}; // builder facts: binary interior nodes, binary leaves, wide nodes with 1..4 children
 	std::vector<FrameCtx*> ctxs; // one per stream that has rendered with this scene
 	bool profiling = false;
@@ -304,7 +306,9 @@ void launch_frame(mirt_scene* s, FrameCtx* c, const DFrame& F, uint8_t* out, hip
 	int launch = 0;
 	c->nLaunches = 0;
 	mark(s, c, st, -1);
-	hipLaunchKernelGGL((k_trace<MODE, OVF, true>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, out, 0, launch++, 0);
+	const bool refill = MODE != MODE_REFWALK && F.refillMin < 64u;
+	if (refill) hipLaunchKernelGGL((k_trace<MODE, OVF, true, true>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, out, 0, launch++, 0);
+	else hipLaunchKernelGGL((k_trace<MODE, OVF, true, false>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, out, 0, launch++, 0);
 	mark(s, c, st, MIRT_K_PRIMARY);
 	if (F.debug != D_PRIMARY_MAP) {
 		const int last = (F.features & F_REFLECTIONS) ? s->maxDepth : 0;
@@ -312,7 +316,8 @@ void launch_frame(mirt_scene* s, FrameCtx* c, const DFrame& F, uint8_t* out, hip
 		for (int depth = 0; depth <= last; ++depth) {
 			const int spawn = depth < last ? 1 : 0; // reflection rays exist while depth+1 <= maxDepth (main.cpp:177)
 			if (spawn || shadowRays) {
-				hipLaunchKernelGGL((k_trace<MODE, OVF, false>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, out, depth + 1, launch++, spawn);
+				if (refill) hipLaunchKernelGGL((k_trace<MODE, OVF, false, true>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, out, depth + 1, launch++, spawn);
+				else hipLaunchKernelGGL((k_trace<MODE, OVF, false, false>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, out, depth + 1, launch++, spawn);
 				mark(s, c, st, MIRT_K_TRACE);
 			}
 			hipLaunchKernelGGL(k_shade, dim3(sgrid), dim3(BLOCK), 0, st, s->ds, F, depth);
@@ -369,6 +374,7 @@ int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 	F.firstTile = p->first_tile; F.tileStride = p->tile_stride;
 	F.features = p->feature_bits; F.debug = p->debug_mode;
 	F.packedTiles = packed ? 1u : 0u;
+	F.refillMin = s->refillMin;
 	HIPCHK(hipEventRecord(c->ev0, st));
 	HIPCHK(hipMemsetAsync(w.counters.p, 0, CTR_COUNT * 4, st));
 	switch (effective_mode(s, p->trace_mode)) {
@@ -665,6 +671,9 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	}
 	s->wideDepth = pk.maxDepth;
 	s->bvhDepth = bvhWideDepth;
+	// Long walks (big scenes) make refilling idle lanes pay; short ones do not (see k_trace).  MIRT_REFILL_MIN overrides.
+	s->refillMin = bvhWide.size() / 16 > 500000u ? 36u : 64u;
+	if (const char* env = getenv("MIRT_REFILL_MIN")) { const int v = atoi(env); if (v >= 1 && v <= 64) s->refillMin = (uint32_t)v; }
 	memcpy(s->diag, bvhDiag, sizeof bvhDiag);
 	ds.bvhRoot = bvhRoot;
 	memcpy(ds.bvhMin, bvhMin, 12);

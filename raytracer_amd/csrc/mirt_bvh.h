@@ -13,6 +13,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -34,14 +35,14 @@ struct BvhNode {
 struct BvhBuilder {
 	static const int BINS = 16;
 #ifndef MIRT_LEAF_MIN
-#define MIRT_LEAF_MIN 2
+#define MIRT_LEAF_MIN 1
 #endif
 #ifndef MIRT_COST_PRIM
-#define MIRT_COST_PRIM 1.5f
+#define MIRT_COST_PRIM 4.0f
 #endif
-	static const uint32_t LEAF_MIN = MIRT_LEAF_MIN; // ranges this small always become a leaf
-	static const uint32_t LEAF_CAP = 8;             // a leaf reference holds a 3-bit count
-	static constexpr float COST_NODE = 1.0f, COST_PRIM = MIRT_COST_PRIM;
+	uint32_t LEAF_MIN = MIRT_LEAF_MIN;  // ranges this small always become a leaf
+	static const uint32_t LEAF_CAP = 8; // a leaf reference holds a 3-bit count
+	float COST_NODE = 1.0f, COST_PRIM = MIRT_COST_PRIM;
 	static const int SAH_DEPTH = 28; // below this depth splits are balanced medians, which bounds the total depth
 
 	std::vector<BvhPrim> prims; // reordered in place: leaf ranges are contiguous
@@ -165,6 +166,9 @@ struct BvhBuilder {
 	}
 
 	void run() {
+		// tuning aid: MIRT_BVH_LEAF_MIN / MIRT_BVH_COST_PRIM override the built-in leaf parameters
+		if (const char* e = getenv("MIRT_BVH_LEAF_MIN")) { const int v = atoi(e); if (v >= 1 && v <= (int)LEAF_CAP) LEAF_MIN = (uint32_t)v; }
+		if (const char* e = getenv("MIRT_BVH_COST_PRIM")) { const float v = (float)atof(e); if (v > 0.0f) COST_PRIM = v; }
 		nodes.clear();
 		maxDepth = 0;
 		if (!prims.empty()) {

@@ -100,6 +100,7 @@ struct DFrame {
 	uint32_t tileW, tileH, tilesX, nTilesLocal, firstTile, tileStride;
 	uint32_t features, debug;
 	uint32_t packedTiles; // output layout: 0 = full image, 1 = packed tile buffer
+	uint32_t refillMin;   // k_trace<REFILL>: parked lanes that trigger a refill
 };
 
 // counters[]: work cursors and statistics, zeroed at the start of every frame

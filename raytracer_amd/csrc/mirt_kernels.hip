@@ -616,16 +616,30 @@ struct Supply {
 	}
 };
 
-#ifndef MIRT_SCHED
-#define MIRT_SCHED 1
-#endif
+// How a wave shares its steps between lanes that stand at an interior node and lanes that stand at a leaf: the group
+// with more (weighted) lanes goes, the other waits.  A primitive test costs more than a node step, hence the weights.
 #ifndef MIRT_NODE_WEIGHT
 #define MIRT_NODE_WEIGHT 1
-#define MIRT_LEAF_WEIGHT 1
+#define MIRT_LEAF_WEIGHT 2
 #endif
-#ifndef MIRT_REFILL_MIN
-#define MIRT_REFILL_MIN 20
-#endif
+
+// Walks every lane's ray to its end.  One step per iteration for the whole wave: either every lane at an interior node
+// takes a node step, or every lane at a leaf tests one primitive.  (Letting each lane run to its next leaf and through
+// it keeps a wave waiting for its longest descent: measured lane utilisation 0.33 on bounce rays against 0.52 this way.)
+template <int MODE, bool OVF>
+__device__ __forceinline__ void walk_wave(const DScene& S, Walker<MODE, OVF>& w, bool& alive, LdsStack<OVF>& stk) {
+	for (;;) {
+		const bool wantNode = alive && w.at_node();
+		const bool wantLeaf = alive && !wantNode;
+		const int nNode = __popcll(__ballot(wantNode)), nLeaf = __popcll(__ballot(wantLeaf));
+		if (nNode + nLeaf == 0) break;
+		if (nNode * MIRT_NODE_WEIGHT >= nLeaf * MIRT_LEAF_WEIGHT) {
+			if (wantNode) w.node_step(S, stk);
+		}
+		else if (wantLeaf) w.leaf_step(S, stk);
+		alive = alive && w.cur != BVH_DONE;
+	}
+}
 
 // ---- the tracing kernel: every ray of one depth in one launch ---------------------------------------------------------------
 // Per-path data (hit records, shadow answers, light sums) is indexed by pixel slot: a pixel has one path (main.cpp:176-201
@@ -639,9 +653,83 @@ struct Supply {
 //   reflection rays (P, R) (main.cpp:188-190); both are derived here from the hit record of depth d-1, so no ray is ever
 //   stored.  Results: a hit record for depth d (nearest-hit rays), or the occluder in F.shRes (shadow queries; the
 //   SHADOW_MAP view asks for the nearest occluder, main.cpp:250-252).
-// A lane whose ray is finished parks its result; once MIRT_REFILL_MIN lanes are parked they write their results
-// together and receive new rays, so the wave does not idle behind its longest ray.
-template <int MODE, bool OVF, bool PRIMARY>
+struct TraceItems {
+	uint32_t nShadowItems;
+	const uint32_t* prevList;
+	size_t rd, wr;
+	int depth;
+};
+
+// The ray of work item `item`.  Returns false for a padding pixel of an edge tile (no ray).
+template <bool PRIMARY>
+__device__ __forceinline__ bool item_ray(const DScene& S, const DFrame& F, const TraceItems& T, uint32_t item, f3& o, f3& d, float& lim, uint32_t& tag, uint32_t& nShadowTraced) {
+	lim = -1.0f;
+	if (PRIMARY) {
+		uint32_t px, py, inTile;
+		const bool live = slot_to_pixel(F, item, px, py, inTile);
+		tag = item;
+		if (!live) F.pathDepth[item] = 0; // no path
+		primary_ray(S, px, py, F.width, F.height, o, d);
+		return live;
+	}
+	const bool shadow = item < T.nShadowItems;
+	const uint32_t h = shadow ? item / S.nLights : item - T.nShadowItems;
+	const uint32_t slot = T.prevList[h];
+	const float4 ho = F.hitO[T.rd + slot], hd = F.hitD[T.rd + slot];
+	const f3 po = F3(ho), pd = F3(hd);
+	o = po + normalize3(pd) * hd.w;                               // P, Camera.cpp:26-28
+	if (shadow) {
+		const uint32_t li = item - h * S.nLights;
+		const float4 ll = S.lights[li * 2];
+		const f3 L = ll.w > 0.0f ? F3(ll) - o : F3(ll);           // main.cpp:213-219
+		d = normalize3(L);                                        // :222
+		lim = F.debug == D_SHADOW_MAP ? -2.0f : length3(L);       // :224
+		tag = slot * S.nLights + li;
+		++nShadowTraced;
+	}
+	else {
+		const f3 N = F3(F.hitN[T.rd + slot]);
+		d = normalize3(pd - N * (2.0f * dot3(pd, N)));            // main.cpp:188
+		tag = slot;
+	}
+	return true;
+}
+
+// Stores the answer of a finished ray.  Returns true if the path goes on (a nearest-hit ray that hit something).
+template <bool PRIMARY>
+__device__ __forceinline__ bool item_result(const DScene& S, const DFrame& F, const TraceItems& T, uint8_t* __restrict__ out, const RayCtx& r, const Hit& best, float limit, uint32_t tag) {
+	const bool hit = best.ref != REF_NONE;
+	if (limit != -1.0f) {
+		F.shRes[tag] = make_uint2(best.ref, __float_as_uint(best.dist));
+		return false;
+	}
+	if (PRIMARY) {
+		if (!hit || F.debug == D_PRIMARY_MAP) {
+			// background is black (main.cpp:124,180); PRIMARY_INTERSECTION_MAP paints hits pure red (main.cpp:183-185)
+			uint32_t px, py, inTile;
+			slot_to_pixel(F, tag, px, py, inTile);
+			const size_t k = out_offset(F, tag, px, py, inTile);
+			out[k] = 0;
+			out[k + 1] = 0;
+			out[k + 2] = hit ? 255 : 0;
+		}
+		F.pathDepth[tag] = (hit && F.debug != D_PRIMARY_MAP) ? 1 : 0;
+	}
+	if (!hit) return false;
+	const f3 n = hit_normal(S, r, best.ref);
+	F.hitO[T.wr + tag] = make_float4(r.o.x, r.o.y, r.o.z, 0.0f);
+	F.hitD[T.wr + tag] = make_float4(r.d.x, r.d.y, r.d.z, best.dist);
+	F.hitN[T.wr + tag] = make_float4(n.x, n.y, n.z, __uint_as_float(best.ref));
+	if (!PRIMARY) F.pathDepth[tag] = (uint8_t)(T.depth + 1);
+	return true;
+}
+
+// REFILL = false: a wave takes 64 items, walks all of them to the end, stores the results and takes the next 64.
+// REFILL = true:  a lane whose ray is finished parks its result; once F.refillMin lanes are parked they store their
+//   results together and receive new rays, so the wave does not idle behind its longest ray.
+// Which one is faster depends on the scene: storing results and setting up rays for a few lanes at a time costs more
+// than it saves while walks are short (Stanford dragon: 7 node steps per ray); with long walks (10 M triangles) it pays.
+template <int MODE, bool OVF, bool PRIMARY, bool REFILL>
 __global__ __launch_bounds__(BLOCK) void k_trace(DScene S, DFrame F, uint8_t* __restrict__ out, int depth, int launch, int spawn) {
 	__shared__ uint32_t s_stack[STACK_LDS * BLOCK];
 	__shared__ uint32_t s_list[BLOCK / WAVE][256];
@@ -652,148 +740,106 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DScene S, DFrame F, uint8_t* __
 	const int lane = threadIdx.x & 63;
 	const unsigned long long ltMask = (1ull << lane) - 1ull;
 	// hit records: read those of depth-1, write those of depth
-	const size_t rd = (size_t)((depth + 1) & 1) * F.nSlots, wr = (size_t)(depth & 1) * F.nSlots;
+	TraceItems T;
+	T.rd = (size_t)((depth + 1) & 1) * F.nSlots;
+	T.wr = (size_t)(depth & 1) * F.nSlots;
+	T.depth = depth;
 	const uint32_t nPrev = PRIMARY ? 0u : F.counters[CTR_NHITS(depth - 1)];
-	const uint32_t nShadowItems = (F.features & F_SHADOWS) ? nPrev * S.nLights : 0u;
-	const uint32_t nTotal = PRIMARY ? F.nSlots : nShadowItems + (spawn ? nPrev : 0u);
-	const uint32_t* prevList = F.active + rd;
-	uint32_t* nextList = F.active + wr;
+	T.nShadowItems = (F.features & F_SHADOWS) ? nPrev * S.nLights : 0u;
+	T.prevList = F.active + T.rd;
+	const uint32_t nTotal = PRIMARY ? F.nSlots : T.nShadowItems + (spawn ? nPrev : 0u);
+	uint32_t* nextList = F.active + T.wr;
 	uint32_t* myList = s_list[threadIdx.x >> 6];
 	uint32_t nbuf = 0;
 	Supply sup(F.counters + CTR_CURSOR(launch), nTotal);
 	Walker<MODE, OVF> w;
-	bool alive = false, parked = false;
-	uint32_t tag = 0;
 	uint32_t nShadowTraced = 0;
+	uint32_t tag = 0;
+	bool alive = false;
+	bool parked = false; // the lane holds a finished ray whose result is not stored yet
 	for (;;) {
-		const int nDead = __popcll(__ballot(!alive));
-		if (sup.exhausted() ? (nDead == 64 || __ballot(parked) != 0ull) : nDead >= MIRT_REFILL_MIN) {
-			// (0) parked lanes make their answer final; the rare ray that fails the check is walked again, strictly
-			if (MODE == MODE_EXACT && parked && !w.verify(S)) {
-				alive = w.start(S, w.r.o, w.r.d, w.limit, true);
-				parked = !alive;
-			}
-			const unsigned long long idle = __ballot(!alive);
-			const int nIdle = __popcll(idle);
-			// (1) parked lanes write their results
-			bool newHit = false;
-			if (parked) {
-				const bool hit = w.best.ref != REF_NONE;
-				if (w.limit == -1.0f) {
-					if (PRIMARY) {
-						if (!hit || F.debug == D_PRIMARY_MAP) {
-							// background is black (main.cpp:124,180); PRIMARY_INTERSECTION_MAP paints hits pure red (main.cpp:183-185)
-							uint32_t px, py, inTile;
-							slot_to_pixel(F, tag, px, py, inTile);
-							const size_t k = out_offset(F, tag, px, py, inTile);
-							out[k] = 0;
-							out[k + 1] = 0;
-							out[k + 2] = hit ? 255 : 0;
-						}
-						F.pathDepth[tag] = (hit && F.debug != D_PRIMARY_MAP) ? 1 : 0;
-					}
-					if (hit) {
-						newHit = true;
-						const f3 n = hit_normal(S, w.r, w.best.ref);
-						F.hitO[wr + tag] = make_float4(w.r.o.x, w.r.o.y, w.r.o.z, 0.0f);
-						F.hitD[wr + tag] = make_float4(w.r.d.x, w.r.d.y, w.r.d.z, w.best.dist);
-						F.hitN[wr + tag] = make_float4(n.x, n.y, n.z, __uint_as_float(w.best.ref));
-						if (!PRIMARY) F.pathDepth[tag] = (uint8_t)(depth + 1);
-					}
-				}
-				else {
-					F.shRes[tag] = make_uint2(w.best.ref, __float_as_uint(w.best.dist));
-				}
-				parked = false;
-			}
-			// slots with a new hit go to this wave's LDS list, which is appended to the next depth's list in large pieces
-			{
-				const unsigned long long hm = __ballot(newHit);
-				if (hm) {
-					if (newHit) myList[nbuf + (uint32_t)__popcll(hm & ltMask)] = tag;
-					nbuf += (uint32_t)__popcll(hm);
-					if (nbuf >= 192u) { flush_list(myList, nbuf, nextList, F.counters + CTR_NHITS(depth)); nbuf = 0; }
-				}
-			}
-			// (2) idle lanes take new items
+		if (!REFILL) {
 			uint32_t base = 0;
-			const uint32_t got = sup.take((uint32_t)nIdle, base);
-			const uint32_t rank = (uint32_t)__popcll(idle & ltMask);
-			if (!alive && rank < got) {
-				const uint32_t item = base + rank;
+			const uint32_t got = sup.take(64u, base);
+			if (got == 0) break;
+			alive = false;
+			parked = false;
+			if ((uint32_t)lane < got) {
 				f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
-				float lim = -1.0f;
-				bool live;
-				if (PRIMARY) {
-					uint32_t px, py, inTile;
-					live = slot_to_pixel(F, item, px, py, inTile);
-					tag = item;
-					if (!live) F.pathDepth[item] = 0; // padding pixel of an edge tile: no path
-					primary_ray(S, px, py, F.width, F.height, o, d);
-				}
-				else {
-					const bool shadow = item < nShadowItems;
-					const uint32_t h = shadow ? item / S.nLights : item - nShadowItems;
-					const uint32_t slot = prevList[h];
-					live = true;
-					if (live) {
-						const float4 ho = F.hitO[rd + slot], hd = F.hitD[rd + slot];
-						const f3 po = F3(ho), pd = F3(hd);
-						o = po + normalize3(pd) * hd.w;                               // P, Camera.cpp:26-28
-						if (shadow) {
-							const uint32_t li = item - h * S.nLights;
-							const float4 ll = S.lights[li * 2];
-							const f3 L = ll.w > 0.0f ? F3(ll) - o : F3(ll);           // main.cpp:213-219
-							d = normalize3(L);                                        // :222
-							lim = F.debug == D_SHADOW_MAP ? -2.0f : length3(L);       // :224
-							tag = slot * S.nLights + li;
-							++nShadowTraced;
-						}
-						else {
-							const f3 N = F3(F.hitN[rd + slot]);
-							d = normalize3(pd - N * (2.0f * dot3(pd, N)));            // main.cpp:188
-							tag = slot;
-						}
-					}
-				}
-				if (live) {
+				float lim;
+				parked = item_ray<PRIMARY>(S, F, T, base + (uint32_t)lane, o, d, lim, tag, nShadowTraced);
+				if (parked) {
 					if (MODE == MODE_REFWALK) {
 						// the reference's own tree, walked in one go (fallback / cross-check mode)
 						w.r = make_ray(o, d);
 						w.limit = lim;
 						trace_whole<MODE_REFWALK, OVF>(S, o, d, lim, w.best, stk);
-						parked = true;
 					}
-					else {
-						alive = w.start(S, o, d, lim);
-						parked = !alive; // missed the whole scene: result is "no hit"
+					else alive = w.start(S, o, d, lim); // false: missed the whole scene, the result is "no hit"
+				}
+			}
+			if (MODE != MODE_REFWALK) {
+				walk_wave(S, w, alive, stk);
+				// deferred check of the final answers; the rare ray that fails it is walked again, strictly
+				if (MODE == MODE_EXACT) {
+					const bool redo = parked && !w.verify(S);
+					if (__ballot(redo)) {
+						if (redo) alive = w.start(S, w.r.o, w.r.d, w.limit, true);
+						walk_wave(S, w, alive, stk);
 					}
+				}
+			}
+		}
+		else {
+			const int nDead = __popcll(__ballot(!alive));
+			if (!(sup.exhausted() ? (nDead == 64 || __ballot(parked) != 0ull) : nDead >= (int)F.refillMin)) {
+				// One step for the whole wave: the larger (weighted) group of lanes goes, see walk_wave
+				const bool wantNode = alive && w.at_node();
+				const bool wantLeaf = alive && !wantNode;
+				const int nNode = __popcll(__ballot(wantNode)), nLeaf = __popcll(__ballot(wantLeaf));
+				if (nNode * MIRT_NODE_WEIGHT >= nLeaf * MIRT_LEAF_WEIGHT) {
+					if (wantNode) w.node_step(S, stk);
+				}
+				else if (wantLeaf) w.leaf_step(S, stk);
+				if (alive && w.cur == BVH_DONE) {
+					alive = false;
+					parked = true;
+				}
+				continue;
+			}
+			// parked lanes make their answer final; the rare ray that fails the check is walked again, strictly
+			if (MODE == MODE_EXACT && parked && !w.verify(S)) {
+				alive = w.start(S, w.r.o, w.r.d, w.limit, true);
+				parked = !alive;
+			}
+		}
+		// finished rays store their results; slots with a new hit go to this wave's LDS list, which is appended to the
+		// next depth's list in large pieces
+		bool newHit = false;
+		if (parked) newHit = item_result<PRIMARY>(S, F, T, out, w.r, w.best, w.limit, tag);
+		parked = false;
+		const unsigned long long hm = __ballot(newHit);
+		if (hm) {
+			if (newHit) myList[nbuf + (uint32_t)__popcll(hm & ltMask)] = tag;
+			nbuf += (uint32_t)__popcll(hm);
+			if (nbuf >= 192u) { flush_list(myList, nbuf, nextList, F.counters + CTR_NHITS(depth)); nbuf = 0; }
+		}
+		if (REFILL) {
+			// idle lanes take new items
+			const unsigned long long idle = __ballot(!alive);
+			uint32_t base = 0;
+			const uint32_t got = sup.take((uint32_t)__popcll(idle), base);
+			const uint32_t rank = (uint32_t)__popcll(idle & ltMask);
+			if (!alive && rank < got) {
+				f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
+				float lim;
+				if (item_ray<PRIMARY>(S, F, T, base + rank, o, d, lim, tag, nShadowTraced)) {
+					alive = w.start(S, o, d, lim);
+					parked = !alive; // missed the whole scene: result is "no hit"
 				}
 			}
 			if (got == 0 && __ballot(alive || parked) == 0ull) break;
 		}
-#if MIRT_SCHED
-		// One step per iteration for the whole wave: either every lane that stands at an interior node takes a node step, or
-		// every lane that stands at a leaf tests one primitive -- whichever group is larger.
-		if (MODE != MODE_REFWALK) {
-			const bool wantNode = alive && w.at_node();
-			const bool wantLeaf = alive && !wantNode;
-			const int nNode = __popcll(__ballot(wantNode)), nLeaf = __popcll(__ballot(wantLeaf));
-			if (nNode * MIRT_NODE_WEIGHT >= nLeaf * MIRT_LEAF_WEIGHT) {
-				if (wantNode) w.node_step(S, stk);
-			}
-			else if (wantLeaf) w.leaf_step(S, stk);
-			if (alive && w.cur == BVH_DONE) {
-				alive = false;
-				parked = true;
-			}
-		}
-#else
-		if (MODE != MODE_REFWALK && alive) {
-			alive = w.advance(S, stk);
-			parked = !alive;
-		}
-#endif
 	}
 	if (nbuf) flush_list(myList, nbuf, nextList, F.counters + CTR_NHITS(depth));
 	// statistics: one atomic per wave
