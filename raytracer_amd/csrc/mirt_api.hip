@@ -328,6 +328,22 @@ void launch_frame(mirt_scene* s, FrameCtx* c, const DFrame& F, uint8_t* out, hip
 	}
 }
 
+FastDiv make_div(uint32_t d) {
+	FastDiv f = {0u, 0xffffffffu, d ? d : 1u, 0u};
+	if (d <= 1) return f;
+	uint32_t lg = 31;
+	while (!(d >> lg)) --lg; // floor(log2 d)
+	if ((d & (d - 1)) == 0) { f.magic = 0; f.shift = lg - 1; return f; }
+	const uint64_t num = 1ull << (32 + lg);
+	uint64_t m = num / d;
+	const uint64_t rem = num % d;
+	m += m;
+	if (2 * rem >= d) m += 1;
+	f.magic = (uint32_t)(m + 1);
+	f.shift = lg;
+	return f;
+}
+
 int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t d_out_bytes, hipStream_t st, bool packed) {
 	uint32_t tileW, tileH;
 	int e = check_params(s, p, tileW, tileH);
@@ -375,8 +391,17 @@ int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 	F.features = p->feature_bits; F.debug = p->debug_mode;
 	F.packedTiles = packed ? 1u : 0u;
 	F.refillMin = s->refillMin;
+	F.divArea = make_div(tileW * tileH);
+	F.divSbx = make_div(tileW >> 3);
+	F.divTilesX = make_div(g.tilesX);
+	// bytes of tiles that are not rendered must stay untouched in the full-image layout, so only clear when all are
+	F.preCleared = (packed || p->tile_stride == 1) ? 1u : 0u;
 	HIPCHK(hipEventRecord(c->ev0, st));
 	HIPCHK(hipMemsetAsync(w.counters.p, 0, CTR_COUNT * 4, st));
+	if (F.preCleared) {
+		HIPCHK(hipMemsetAsync(d_out, 0, need, st));
+		HIPCHK(hipMemsetAsync(w.pathDepth.p, 0, n, st));
+	}
 	switch (effective_mode(s, p->trace_mode)) {
 	case MODE_FAST:
 		if (s->deepBvh) launch_frame<MODE_FAST, true>(s, c, F, (uint8_t*)d_out, st);

@@ -84,6 +84,12 @@ struct DScene {
 	DCamera cam;
 };
 
+// Division by a number fixed for the launch: q = ((x - hi(x * magic)) >> 1) + hi(x * magic)) >> shift, exact for every
+// 32-bit x and every divisor >= 2 (round-up method with a 33-bit multiplier, the add folded in); shift = ~0u marks d == 1.
+struct FastDiv {
+	uint32_t magic, shift, d, pad;
+};
+
 // One frame's working set.  Every array is indexed by pixel slot: a pixel has exactly one path.
 struct DFrame {
 	float4* hitO;      // hit records, two sets of nSlots (depth parity): { ray o.xyz, 0 }
@@ -101,6 +107,8 @@ struct DFrame {
 	uint32_t features, debug;
 	uint32_t packedTiles; // output layout: 0 = full image, 1 = packed tile buffer
 	uint32_t refillMin;   // k_trace<REFILL>: parked lanes that trigger a refill
+	uint32_t preCleared;  // the output buffer and pathDepth were zeroed before the frame: missed primary rays store nothing
+	FastDiv divArea, divSbx, divTilesX; // tile area, 8x8 blocks per tile row, tiles per image row
 };
 
 // counters[]: work cursors and statistics, zeroed at the start of every frame

@@ -92,8 +92,9 @@ __device__ __forceinline__ RayCtx make_ray(f3 o, f3 d) {
 	const float sx = fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x;
 	const float sy = fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y;
 	const float sz = fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z;
-	r.ie = F3(1.0f / sx, 1.0f / sy, 1.0f / sz);
-	r.invLen = inv_sqrt(dot3(d, d));
+	// v_rcp_f32 / v_rsq_f32 are within 1 ulp: far inside the filter's padding and the 1e-4 culling slack
+	r.ie = F3(__builtin_amdgcn_rcpf(sx), __builtin_amdgcn_rcpf(sy), __builtin_amdgcn_rcpf(sz));
+	r.invLen = __builtin_amdgcn_rsqf(dot3(d, d));
 	r.oie = r.o * r.ie;
 	return r;
 }
@@ -325,7 +326,9 @@ __device__ __forceinline__ uint32_t membership(const DScene& S, const RayCtx& r,
 	return REF_NONE;
 }
 
+#ifndef STACK_LDS
 #define STACK_LDS 32
+#endif
 
 // Traversal stack: STACK_LDS entries per lane in LDS ([entry][lane]: conflict-free, no address arithmetic beyond a
 // shift).  Hierarchies deeper than that (OVF = true, chosen by the host from the built depth) keep the deeper entries in
@@ -555,20 +558,25 @@ __device__ __forceinline__ void primary_ray(const DScene& S, uint32_t px, uint32
 
 // slot -> pixel.  A slot is (local tile, 8x8 sub-block, lane): 64 consecutive slots are one 8x8 pixel block, so a
 // wave's primary rays are spatially coherent.  Returns false for padding pixels of edge tiles.
+__device__ __forceinline__ uint32_t fast_div(uint32_t x, const FastDiv& f) {
+	if (f.shift == 0xffffffffu) return x;
+	const uint32_t q = __umulhi(x, f.magic);
+	return (((x - q) >> 1) + q) >> f.shift;
+}
 __device__ __forceinline__ bool slot_to_pixel(const DFrame& F, uint32_t slot, uint32_t& px, uint32_t& py, uint32_t& inTile) {
-	const uint32_t tileArea = F.tileW * F.tileH;
-	const uint32_t lt = slot / tileArea, i = slot % tileArea;
+	const uint32_t lt = fast_div(slot, F.divArea), i = slot - lt * F.divArea.d;
 	const uint32_t sb = i >> 6, l = i & 63;
-	const uint32_t sbx = F.tileW >> 3;
-	const uint32_t tx = (sb % sbx) * 8 + (l & 7), ty = (sb / sbx) * 8 + (l >> 3);
+	const uint32_t sby = fast_div(sb, F.divSbx), sbxi = sb - sby * F.divSbx.d;
+	const uint32_t tx = sbxi * 8 + (l & 7), ty = sby * 8 + (l >> 3);
 	const uint32_t k = F.firstTile + lt * F.tileStride;
-	px = (k % F.tilesX) * F.tileW + tx;
-	py = (k / F.tilesX) * F.tileH + ty;
+	const uint32_t ky = fast_div(k, F.divTilesX), kx = k - ky * F.divTilesX.d;
+	px = kx * F.tileW + tx;
+	py = ky * F.tileH + ty;
 	inTile = ty * F.tileW + tx;
 	return px < F.width && py < F.height;
 }
 __device__ __forceinline__ size_t out_offset(const DFrame& F, uint32_t slot, uint32_t px, uint32_t py, uint32_t inTile) {
-	if (F.packedTiles) return ((size_t)(slot / (F.tileW * F.tileH)) * (F.tileW * F.tileH) + inTile) * 3;
+	if (F.packedTiles) return ((size_t)fast_div(slot, F.divArea) * F.divArea.d + inTile) * 3;
 	return ((size_t)py * F.width + px) * 3; // main.cpp:154-156
 }
 
@@ -668,7 +676,7 @@ __device__ __forceinline__ bool item_ray(const DScene& S, const DFrame& F, const
 		uint32_t px, py, inTile;
 		const bool live = slot_to_pixel(F, item, px, py, inTile);
 		tag = item;
-		if (!live) F.pathDepth[item] = 0; // no path
+		if (!live && !F.preCleared) F.pathDepth[item] = 0; // no path
 		primary_ray(S, px, py, F.width, F.height, o, d);
 		return live;
 	}
@@ -704,8 +712,9 @@ __device__ __forceinline__ bool item_result(const DScene& S, const DFrame& F, co
 		return false;
 	}
 	if (PRIMARY) {
-		if (!hit || F.debug == D_PRIMARY_MAP) {
-			// background is black (main.cpp:124,180); PRIMARY_INTERSECTION_MAP paints hits pure red (main.cpp:183-185)
+		// background is black (main.cpp:124,180); PRIMARY_INTERSECTION_MAP paints hits pure red (main.cpp:183-185)
+		const bool red = hit && F.debug == D_PRIMARY_MAP;
+		if (red || (!hit && !F.preCleared)) {
 			uint32_t px, py, inTile;
 			slot_to_pixel(F, tag, px, py, inTile);
 			const size_t k = out_offset(F, tag, px, py, inTile);
@@ -713,7 +722,8 @@ __device__ __forceinline__ bool item_result(const DScene& S, const DFrame& F, co
 			out[k + 1] = 0;
 			out[k + 2] = hit ? 255 : 0;
 		}
-		F.pathDepth[tag] = (hit && F.debug != D_PRIMARY_MAP) ? 1 : 0;
+		const bool goesOn = hit && !red;
+		if (goesOn || !F.preCleared) F.pathDepth[tag] = goesOn ? 1 : 0;
 	}
 	if (!hit) return false;
 	const f3 n = hit_normal(S, r, best.ref);
@@ -729,8 +739,11 @@ __device__ __forceinline__ bool item_result(const DScene& S, const DFrame& F, co
 //   results together and receive new rays, so the wave does not idle behind its longest ray.
 // Which one is faster depends on the scene: storing results and setting up rays for a few lanes at a time costs more
 // than it saves while walks are short (Stanford dragon: 7 node steps per ray); with long walks (10 M triangles) it pays.
+#ifndef MIRT_TRACE_ATTR
+#define MIRT_TRACE_ATTR
+#endif
 template <int MODE, bool OVF, bool PRIMARY, bool REFILL>
-__global__ __launch_bounds__(BLOCK) void k_trace(DScene S, DFrame F, uint8_t* __restrict__ out, int depth, int launch, int spawn) {
+__global__ __launch_bounds__(BLOCK) MIRT_TRACE_ATTR void k_trace(DScene S, DFrame F, uint8_t* __restrict__ out, int depth, int launch, int spawn) {
 	__shared__ uint32_t s_stack[STACK_LDS * BLOCK];
 	__shared__ uint32_t s_list[BLOCK / WAVE][256];
 	LdsStack<OVF> stk;
@@ -747,10 +760,10 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DScene S, DFrame F, uint8_t* __
 	const uint32_t nPrev = PRIMARY ? 0u : F.counters[CTR_NHITS(depth - 1)];
 	T.nShadowItems = (F.features & F_SHADOWS) ? nPrev * S.nLights : 0u;
 	T.prevList = F.active + T.rd;
-	const uint32_t nTotal = PRIMARY ? F.nSlots : T.nShadowItems + (spawn ? nPrev : 0u);
 	uint32_t* nextList = F.active + T.wr;
 	uint32_t* myList = s_list[threadIdx.x >> 6];
 	uint32_t nbuf = 0;
+	const uint32_t nTotal = PRIMARY ? F.nSlots : T.nShadowItems + (spawn ? nPrev : 0u);
 	Supply sup(F.counters + CTR_CURSOR(launch), nTotal);
 	Walker<MODE, OVF> w;
 	uint32_t nShadowTraced = 0;
