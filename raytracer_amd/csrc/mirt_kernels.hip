@@ -432,14 +432,13 @@ struct Walker {
 		if (key[1] != 0xffffffffu) { stk.push(sp, ref[1]); ++sp; }
 	}
 
-	// One primitive of the current leaf (1..8 consecutive records of one kind).  Call only while cur is a leaf.
-	// Afterwards cur is the rest of the leaf, or the next stack entry, or BVH_DONE.  Returns true while the same leaf goes on.
-	__device__ __forceinline__ bool leaf_step(const DScene& S, LdsStack<OVF>& stk) {
+	// Tests the first record of leaf reference `lf` against the ray and updates the best hit.  Returns true if the walk
+	// is over (a shadow query found its occluder, or a distance tie asks for the strict walk).
+	__device__ __forceinline__ bool test_first(const DScene& S, uint32_t lf) {
 		STAT_WAVE(S, 2); // primitive tests (wave iterations)
 		STAT_LANE(S, 3); // primitive tests (lanes)
-		const uint32_t idx = cur & BVH_FIRST_MASK;
-		const bool sph = (cur & BVH_SPHERES) != 0;
-		const bool more = ((cur >> BVH_COUNT_SHIFT) & 7u) != 0u;
+		const uint32_t idx = lf & BVH_FIRST_MASK;
+		const bool sph = (lf & BVH_SPHERES) != 0;
 		const bool any = limit >= 0.0f;
 		float dist;
 		if (sph) {
@@ -449,44 +448,50 @@ struct Walker {
 		else {
 			dist = tri_hit<MODE>(r, S.tris + (size_t)idx * 4, tcull);
 		}
-		if (dist >= 0.0f && !isinf(dist)) {
-			const uint32_t ref = sph ? (PRIM_SPHERE | idx) : idx;
-			const bool tie = !any && dist == best.dist && ref != best.ref;
-			bool cand = any ? (dist < limit) : (dist < best.dist || tie);
-			uint32_t pos = 0;
-			if (cand && MODE == MODE_EXACT) {
-				if (!strict) {
-					if (tie) { needStrict = true; cur = BVH_DONE; return false; }
-				}
-				else {
-					STAT_WAVE(S, 4); // membership checks (wave)
-					STAT_LANE(S, 5); // membership checks (lanes)
-					const uint4 info = sph ? S.sphInfo[idx] : S.triInfo[idx];
-					pos = membership(S, r, info.z, info.w);
-					if (pos == REF_NONE) cand = false; // the reference's tree never reaches this primitive along this ray
-				}
+		if (!(dist >= 0.0f) || isinf(dist)) return false;
+		const uint32_t ref = sph ? (PRIM_SPHERE | idx) : idx;
+		const bool tie = !any && dist == best.dist && ref != best.ref;
+		const bool cand = any ? (dist < limit) : (dist < best.dist || tie);
+		if (!cand) return false;
+		uint32_t pos = 0;
+		if (MODE == MODE_EXACT) {
+			if (!strict) {
+				if (tie) { needStrict = true; return true; }
 			}
-			if (cand) {
-				if (any) {
-					best.dist = dist;
-					best.ref = ref;
-					best.pos = pos;
-					cur = BVH_DONE;
-					return false;
-				}
-				// Partition.h:33 (first in a leaf wins), Partition.cpp:47 (left subtree wins) == lower visiting rank wins
-				if (dist < best.dist || pos < best.pos) {
-					best.dist = dist;
-					best.ref = ref;
-					best.pos = pos;
-					tcull = dist * r.invLen * 1.0001f + 1e-5f;
-				}
+			else {
+				STAT_WAVE(S, 4); // membership checks (wave)
+				STAT_LANE(S, 5); // membership checks (lanes)
+				const uint4 info = sph ? S.sphInfo[idx] : S.triInfo[idx];
+				pos = membership(S, r, info.z, info.w);
+				if (pos == REF_NONE) return false; // the reference's tree never reaches this primitive along this ray
 			}
 		}
-		if (more) {
-			cur = cur - (1u << BVH_COUNT_SHIFT) + 1u; // one record fewer, starting one further
+		if (any) {
+			best.dist = dist;
+			best.ref = ref;
+			best.pos = pos;
 			return true;
 		}
+		// Partition.h:33 (first in a leaf wins), Partition.cpp:47 (left subtree wins) == lower visiting rank wins
+		if (dist < best.dist || pos < best.pos) {
+			best.dist = dist;
+			best.ref = ref;
+			best.pos = pos;
+			tcull = dist * r.invLen * 1.0001f + 1e-5f;
+		}
+		return false;
+	}
+	// a leaf reference without its first record, or 0 if that was the last one
+	static __device__ __forceinline__ uint32_t leaf_rest(uint32_t lf) {
+		return ((lf >> BVH_COUNT_SHIFT) & 7u) ? lf - (1u << BVH_COUNT_SHIFT) + 1u : 0u;
+	}
+
+	// One primitive of the current leaf (1..8 consecutive records of one kind).  Call only while cur is a leaf.
+	// Afterwards cur is the rest of the leaf, or the next stack entry, or BVH_DONE.  Returns true while the same leaf goes on.
+	__device__ __forceinline__ bool leaf_step(const DScene& S, LdsStack<OVF>& stk) {
+		if (test_first(S, cur)) { cur = BVH_DONE; sp = 0; return false; }
+		const uint32_t rest = leaf_rest(cur);
+		if (rest) { cur = rest; return true; }
 		cur = sp > 0 ? stk.pop(--sp) : BVH_DONE;
 		return false;
 	}
@@ -636,6 +641,8 @@ struct Supply {
 // it keeps a wave waiting for its longest descent: measured lane utilisation 0.33 on bounce rays against 0.52 this way.)
 template <int MODE, bool OVF>
 __device__ __forceinline__ void walk_wave(const DScene& S, Walker<MODE, OVF>& w, bool& alive, LdsStack<OVF>& stk) {
+	// (Tried and dropped: letting a lane put the leaf it reaches into a small queue of its own and go on with its stack,
+	// so that primitive steps would find more lanes ready -- primitive steps became more frequent and emptier instead.)
 	for (;;) {
 		const bool wantNode = alive && w.at_node();
 		const bool wantLeaf = alive && !wantNode;
