@@ -569,7 +569,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 
 	// 4-wide nodes with quantised child boxes (layout in mirt_device.h)
 	std::vector<uint32_t> bvhWide;
-	uint32_t bvhRoot = BVH_DONE, bvhWideDepth = 0;
+	uint32_t bvhRoot = BVH_DONE, bvhWideDepth = 0, bvhMaxStack = 0;
 	uint32_t bvhDiag[8] = {0};
 	float bvhMin[3] = {0, 0, 0}, bvhMax[3] = {-1, -1, -1};
 	if (!bb.nodes.empty()) {
@@ -582,7 +582,9 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 			uint32_t leafRef(const BvhNode& n) const {
 				return BVH_LEAF | (n.kind ? BVH_SPHERES : 0u) | ((n.count - 1) << BVH_COUNT_SHIFT) | kindIndex[n.first];
 			}
-			uint32_t emit(int32_t i, uint32_t depth) {
+			uint32_t maxStack = 0;
+			// acc: entries the walk can hold on its stack when it arrives at this node (siblings left behind by the ancestors)
+			uint32_t emit(int32_t i, uint32_t depth, uint32_t acc = 0) {
 				if (depth > maxDepth) maxDepth = depth;
 				const uint32_t me = (uint32_t)(out.size() / 16);
 				out.resize(out.size() + 16, 0u);
@@ -639,15 +641,18 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 					w[7] |= qhi[0] << (8 * c); w[8] |= qhi[1] << (8 * c); w[9] |= qhi[2] << (8 * c);
 				}
 				diag[1 + n]++;
+				const uint32_t below = acc + (uint32_t)n - 1u; // a step pushes every hit child but the one it goes to
+				if (below > maxStack) maxStack = below;
 				memcpy(out.data() + (size_t)me * 16, w, sizeof w);
-				for (int c = 0; c < n; ++c) refs[c] = bb.nodes[ch[c]].left < 0 ? leafRef(bb.nodes[ch[c]]) : emit(ch[c], depth + 1);
+				for (int c = 0; c < n; ++c) refs[c] = bb.nodes[ch[c]].left < 0 ? leafRef(bb.nodes[ch[c]]) : emit(ch[c], depth + 1, below);
 				memcpy(out.data() + (size_t)me * 16 + 10, refs, sizeof refs);
 				return me;
 			}
-		} em = {bb, kindIndex, bvhWide, 0, bvhDiag};
+		} em = {bb, kindIndex, bvhWide, 0, bvhDiag, 0};
 		for (const BvhNode& bn : bb.nodes) bvhDiag[bn.left < 0 ? 1 : 0]++;
 		bvhRoot = bb.nodes[0].left < 0 ? em.leafRef(bb.nodes[0]) : em.emit(0, 1);
 		bvhWideDepth = em.maxDepth;
+		bvhMaxStack = em.maxStack;
 		memcpy(bvhMin, bb.nodes[0].lo, 12);
 		memcpy(bvhMax, bb.nodes[0].hi, 12);
 	}
@@ -793,8 +798,9 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	ds.dbg = (unsigned long long*)s->dbg.p;
 	ds.ovf = nullptr;
 	ds.ovfStride = (uint32_t)s->numCUs * GRID_BLOCKS_PER_CU * BLOCK;
-	// a step pushes up to three siblings, so a walk can hold 3 entries per level
-	const uint32_t stackNeed = 3u * bvhWideDepth + 1u;
+	// the most entries a walk can hold: along any path, every node leaves behind all its children but one
+	const uint32_t stackNeed = bvhMaxStack + 1u;
+	s->diag[6] = stackNeed;
 	s->deepBvh = stackNeed > STACK_LDS;
 	if (!e && s->deepBvh) {
 		e = s->ovf.ensure((size_t)(stackNeed - STACK_LDS) * ds.ovfStride * 4);

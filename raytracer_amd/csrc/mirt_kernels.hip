@@ -339,13 +339,21 @@ struct LdsStack {
 	uint32_t* lds;   // this thread's column
 	uint32_t* ovf;   // [level][global thread], this thread's column
 	uint32_t ovfStride;
+	// The overflow accesses are written as inline asm on purpose: given two plain loads, one from LDS and one from global
+	// memory, the compiler merges them into a single FLAT load through a selected pointer, which makes every pop slow.
 	__device__ __forceinline__ void push(int sp, uint32_t v) {
 		if (!OVF || sp < STACK_LDS) lds[sp * BLOCK] = v;
-		else __builtin_nontemporal_store(v, ovf + (size_t)(sp - STACK_LDS) * ovfStride);
+		else {
+			uint32_t* p = ovf + (size_t)(sp - STACK_LDS) * ovfStride;
+			asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+		}
 	}
 	__device__ __forceinline__ uint32_t pop(int sp) {
 		if (!OVF || sp < STACK_LDS) return lds[sp * BLOCK];
-		return __builtin_nontemporal_load(ovf + (size_t)(sp - STACK_LDS) * ovfStride);
+		uint32_t v;
+		const uint32_t* p = ovf + (size_t)(sp - STACK_LDS) * ovfStride;
+		asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+		return v;
 	}
 };
 
