@@ -414,17 +414,22 @@ struct Walker {
 		const float bz = __builtin_fmaf(__uint_as_float(q0.z), r.ie.z, -r.oie.z);
 		uint32_t key[4], ref[4];
 		ref[0] = q2.z; ref[1] = q2.w; ref[2] = q3.x; ref[3] = q3.y;
+		typedef float pk2 __attribute__((ext_vector_type(2))); // both planes of an axis in one packed FMA
+		const pk2 pax = {ax, ax}, pay = {ay, ay}, paz = {az, az}, pbx = {bx, bx}, pby = {by, by}, pbz = {bz, bz};
+		// entry no earlier than the ray's start, exit no later than the culling bound (which is never negative):
+		// max(tmin, 0) <= min(tmax, tcull)  <=>  tmin <= tmax and tmax >= 0 and tmin <= tcull
 #pragma unroll
 		for (int c = 0; c < 4; ++c) {
 			const int sh = 8 * c;
-			const float t1 = __builtin_fmaf((float)((q1.x >> sh) & 0xffu), ax, bx), t2 = __builtin_fmaf((float)((q1.w >> sh) & 0xffu), ax, bx);
-			const float t3 = __builtin_fmaf((float)((q1.y >> sh) & 0xffu), ay, by), t4 = __builtin_fmaf((float)((q2.x >> sh) & 0xffu), ay, by);
-			const float t5 = __builtin_fmaf((float)((q1.z >> sh) & 0xffu), az, bz), t6 = __builtin_fmaf((float)((q2.y >> sh) & 0xffu), az, bz);
-			const float tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
-			const float tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
-			const bool hit = (tmin <= tmax) && (tmax >= 0.0f) && !(tmin > tcull) && ref[c] != BVH_DONE;
+			const pk2 qx = {(float)((q1.x >> sh) & 0xffu), (float)((q1.w >> sh) & 0xffu)};
+			const pk2 qy = {(float)((q1.y >> sh) & 0xffu), (float)((q2.x >> sh) & 0xffu)};
+			const pk2 qz = {(float)((q1.z >> sh) & 0xffu), (float)((q2.y >> sh) & 0xffu)};
+			const pk2 tx = __builtin_elementwise_fma(qx, pax, pbx), ty = __builtin_elementwise_fma(qy, pay, pby), tz = __builtin_elementwise_fma(qz, paz, pbz);
+			const float tmin = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), 0.0f));
+			const float tmax = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), tcull));
+			const bool hit = (tmin <= tmax) && ref[c] != BVH_DONE;
 			// non-negative floats order like their bit patterns
-			key[c] = hit ? __float_as_uint(fmaxf(tmin, 0.0f)) : 0xffffffffu;
+			key[c] = hit ? __float_as_uint(tmin) : 0xffffffffu;
 		}
 #define MIRT_CSWAP(i, j) { const bool sw = key[j] < key[i]; const uint32_t ki = key[i], ri = ref[i]; \
 		key[i] = sw ? key[j] : ki; ref[i] = sw ? ref[j] : ri; key[j] = sw ? ki : key[j]; ref[j] = sw ? ri : ref[j]; }

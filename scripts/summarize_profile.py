@@ -3,6 +3,7 @@
 import collections
 import csv
 import glob
+import re
 import json
 import os
 import shutil
@@ -27,7 +28,7 @@ def load(path):
 def last_frame(d):
     """dispatches of the last frame: from the last primary tracing launch to the end"""
     keys = list(d.keys())
-    start = max(i for i, k in enumerate(keys) if "true>" in k[1] and "k_trace" in k[1])
+    start = max(i for i, k in enumerate(keys) if re.search(r"k_trace<\d+, (true|false), true,", k[1]))  # <MODE, OVF, PRIMARY, REFILL>
     return [(k, d[k]) for k in keys[start:] if k[1].startswith(("void k_", "k_"))]
 
 
