@@ -212,6 +212,16 @@ int validate_desc(const mirt_scene_desc* d) {
 		if (d->tri_prim[i] >= d->n_prims) return fail(MIRT_E_INVALID, "tri_prim[%u] out of range", i);
 	for (uint32_t i = 0; i < d->n_spheres; ++i)
 		if (d->sphere_prim[i] >= d->n_prims) return fail(MIRT_E_INVALID, "sphere_prim[%u] out of range", i);
+	// Non-finite geometry: with a non-invertible transform glm::inverse is inf/NaN and Sphere::intersect (Sphere.cpp:59-83)
+	// returns a NaN distance, which Intersection::isValidIntersection (SceneObjects.hpp:35-37) takes for a hit; what the
+	// reference then draws depends on the order of NaN comparisons all the way up its tree.  Rejected here instead.
+	for (uint32_t i = 0; i < d->n_spheres; ++i) {
+		const float* f = &d->spheres[i].center[0];
+		for (int k = 0; k < 36; ++k)
+			if (!isfinite(f[k])) return fail(MIRT_E_INVALID, "sphere %u: non-finite centre, radius, transform or inverse transform (singular transform?)", i);
+	}
+	for (uint64_t i = 0; i < (uint64_t)d->n_triangles * 9; ++i)
+		if (!isfinite(d->tri_verts[i])) return fail(MIRT_E_INVALID, "triangle %llu: non-finite vertex", (unsigned long long)(i / 9));
 	for (uint32_t i = 0; i < d->n_prims; ++i)
 		if (d->prim_material[i] >= d->n_materials) return fail(MIRT_E_INVALID, "prim_material[%u] out of range", i);
 	return MIRT_OK;
@@ -361,6 +371,8 @@ int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 	if (s->maxDepth < 0) {
 		// depth 0 already exceeds maxDepth: computePixelColor returns Color() for every pixel (main.cpp:177,199)
 		HIPCHK(hipMemsetAsync(d_out, 0, need, st));
+		c->lastPrimary = g.livePixels; // the camera ray of every pixel is still made (main.cpp:152)
+		c->lastFeatures = p->feature_bits;
 		return MIRT_OK;
 	}
 	Workspace& w = c->ws;

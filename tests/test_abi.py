@@ -3,6 +3,8 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
+
 from conftest import ROOT
 from raytracer_amd import _capi
 
@@ -41,3 +43,15 @@ def test_invalid_arguments_are_rejected_without_a_device():
     assert lib.mirt_tile_buffer_bytes(C.byref(p)) == 32 * 32 * 3
     p0 = _capi.make_params(100, 50)
     assert lib.mirt_tile_buffer_bytes(C.byref(p0)) == 100 * 50 * 3
+
+
+def test_non_finite_geometry_is_rejected_before_any_device_call():
+    import ctypes as C
+    from raytracer_amd.scene import FlatScene
+    lib = _capi.load_library()
+    fs = FlatScene.from_text("size 8 8\ncamera 0 0 4 0 0 0 0 1 0 45\npushTransform\nscale 1 0 1\nsphere 0 0 0 1\npopTransform\n")
+    assert not np.isfinite(fs.spheres).all()   # glm::inverse of the singular matrix, as the reference computes it
+    d = fs.desc()
+    h = C.c_void_p()
+    assert lib.mirt_scene_create(C.byref(d), 0, C.byref(h)) == -1
+    assert b"singular" in lib.mirt_last_error()
