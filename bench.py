@@ -114,7 +114,7 @@ def main():
     nbytes = multigpu.per_rank_bytes(width, height, world) if world > 1 else width * height * 3
     # frames are issued round-robin on `pipeline` streams; the library keeps one workspace per stream, so the short
     # latency-bound deep-bounce launches of one frame overlap the bulk of the next
-    depth = args.pipeline if args.pipeline > 0 else (2 if world == 1 else 4)
+    depth = args.pipeline if args.pipeline > 0 else 6
     streams = [torch.cuda.Stream() for _ in range(depth)]
     locals_ = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(depth)]
     images = [torch.empty(width * height * 3, dtype=torch.uint8, device="cuda") for _ in range(depth)] if (world > 1 and rank == 0) else None
