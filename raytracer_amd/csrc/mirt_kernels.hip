@@ -655,7 +655,11 @@ struct Supply {
 template <int MODE, bool OVF>
 __device__ __forceinline__ void walk_wave(const DScene& S, Walker<MODE, OVF>& w, bool& alive, LdsStack<OVF>& stk) {
 	// (Tried and dropped: letting a lane put the leaf it reaches into a small queue of its own and go on with its stack,
-	// so that primitive steps would find more lanes ready -- primitive steps became more frequent and emptier instead.)
+	// so that primitive steps would find more lanes ready -- primitive steps became more frequent and emptier instead.
+	// Also tried and dropped: setting the last <= 12 walking rays of a batch aside (state and stack to a per-wave slice of
+	// global memory) and resuming them 64 at a time at the end of the launch.  On the Stanford dragon 40 % of all lane
+	// slots belong to rays that are already finished, but the number of walking lanes decays gradually rather than
+	// leaving a few stragglers: the wave iterations fell by 7 % only, which the extra registers ate.)
 	for (;;) {
 		const bool wantNode = alive && w.at_node();
 		const bool wantLeaf = alive && !wantNode;
