@@ -813,9 +813,10 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	// the most entries a walk can hold: along any path, every node leaves behind all its children but one
 	const uint32_t stackNeed = bvhMaxStack + 1u;
 	s->diag[6] = stackNeed;
-	s->deepBvh = stackNeed > STACK_LDS;
+	const uint32_t ldsEntries = s->refillMin < 64u ? STACK_LDS_REFILL : STACK_LDS; // see launch_frame: which k_trace variant runs
+	s->deepBvh = stackNeed > ldsEntries;
 	if (!e && s->deepBvh) {
-		e = s->ovf.ensure((size_t)(stackNeed - STACK_LDS) * ds.ovfStride * 4);
+		e = s->ovf.ensure((size_t)(stackNeed - ldsEntries) * ds.ovfStride * 4);
 		ds.ovf = (uint32_t*)s->ovf.p;
 	}
 	if (!e && hipStreamCreate(&s->stream) != hipSuccess) e = fail(MIRT_E_DEVICE, "hipStreamCreate failed");

@@ -329,12 +329,16 @@ __device__ __forceinline__ uint32_t membership(const DScene& S, const RayCtx& r,
 #ifndef STACK_LDS
 #define STACK_LDS 32
 #endif
+// The lane-refilling variant of k_trace serves big scenes, where waves wait for memory rather than for the VALU: it is
+// compiled for 6 waves per SIMD (80 VGPRs) and keeps only 20 stack entries per lane in LDS so that 6 blocks fit a CU
+// (10 M triangles: 2.24 -> 2.76 Grays/s against 4 waves; 7 and 8 waves spill too much and lose).
+#define STACK_LDS_REFILL 20
 
 // Traversal stack: STACK_LDS entries per lane in LDS ([entry][lane]: conflict-free, no address arithmetic beyond a
 // shift).  Hierarchies deeper than that (OVF = true, chosen by the host from the built depth) keep the deeper entries in
 // a global array; the two cases are separate instantiations so that the common one contains LDS instructions only
 // (a merged pointer would turn every pop into a flat_load).
-template <bool OVF>
+template <bool OVF, int NLDS = STACK_LDS>
 struct LdsStack {
 	uint32_t* lds;   // this thread's column
 	uint32_t* ovf;   // [level][global thread], this thread's column
@@ -342,16 +346,16 @@ struct LdsStack {
 	// The overflow accesses are written as inline asm on purpose: given two plain loads, one from LDS and one from global
 	// memory, the compiler merges them into a single FLAT load through a selected pointer, which makes every pop slow.
 	__device__ __forceinline__ void push(int sp, uint32_t v) {
-		if (!OVF || sp < STACK_LDS) lds[sp * BLOCK] = v;
+		if (!OVF || sp < NLDS) lds[sp * BLOCK] = v;
 		else {
-			uint32_t* p = ovf + (size_t)(sp - STACK_LDS) * ovfStride;
+			uint32_t* p = ovf + (size_t)(sp - NLDS) * ovfStride;
 			asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
 		}
 	}
 	__device__ __forceinline__ uint32_t pop(int sp) {
-		if (!OVF || sp < STACK_LDS) return lds[sp * BLOCK];
+		if (!OVF || sp < NLDS) return lds[sp * BLOCK];
 		uint32_t v;
-		const uint32_t* p = ovf + (size_t)(sp - STACK_LDS) * ovfStride;
+		const uint32_t* p = ovf + (size_t)(sp - NLDS) * ovfStride;
 		asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
 		return v;
 	}
@@ -401,7 +405,8 @@ struct Walker {
 	// and push the other hit children, farthest first; none hit: pop.  Call only while at_node().
 	// The quantised boxes contain the padded primitive bounds (lower bounds rounded down, upper bounds up), so the filter
 	// stays conservative; see box_filter for the rounding argument.
-	__device__ __forceinline__ void node_step(const DScene& S, LdsStack<OVF>& stk) {
+	template <class STK>
+	__device__ __forceinline__ void node_step(const DScene& S, STK& stk) {
 		STAT_WAVE(S, 0); // node steps (wave iterations)
 		STAT_LANE(S, 1); // node steps (lanes)
 		const uint4* nd = (const uint4*)S.bvh + (size_t)cur * 4;
@@ -501,7 +506,8 @@ struct Walker {
 
 	// One primitive of the current leaf (1..8 consecutive records of one kind).  Call only while cur is a leaf.
 	// Afterwards cur is the rest of the leaf, or the next stack entry, or BVH_DONE.  Returns true while the same leaf goes on.
-	__device__ __forceinline__ bool leaf_step(const DScene& S, LdsStack<OVF>& stk) {
+	template <class STK>
+	__device__ __forceinline__ bool leaf_step(const DScene& S, STK& stk) {
 		if (test_first(S, cur)) { cur = BVH_DONE; sp = 0; return false; }
 		const uint32_t rest = leaf_rest(cur);
 		if (rest) { cur = rest; return true; }
@@ -510,7 +516,8 @@ struct Walker {
 	}
 
 	// One round: descend to the next leaf, test its primitives, pop.  Returns false when the walk is over.
-	__device__ __forceinline__ bool advance(const DScene& S, LdsStack<OVF>& stk) {
+	template <class STK>
+	__device__ __forceinline__ bool advance(const DScene& S, STK& stk) {
 		STAT_WAVE(S, 6); // advance rounds (wave)
 		STAT_LANE(S, 7); // advance rounds (lanes)
 		while (at_node()) node_step(S, stk);
@@ -532,8 +539,8 @@ struct Walker {
 };
 
 // whole walk at once (test hooks and MODE_REFWALK dispatch)
-template <int MODE, bool OVF>
-__device__ __forceinline__ void trace_whole(const DScene& S, f3 o, f3 d, float limit, Hit& best, LdsStack<OVF>& stk) {
+template <int MODE, bool OVF, class STK>
+__device__ __forceinline__ void trace_whole(const DScene& S, f3 o, f3 d, float limit, Hit& best, STK& stk) {
 	if (MODE == MODE_REFWALK) {
 		const RayCtx r = make_ray(o, d);
 		if (limit >= 0.0f) traverse_ref<true>(S, r, limit, best);
@@ -652,8 +659,8 @@ struct Supply {
 // Walks every lane's ray to its end.  One step per iteration for the whole wave: either every lane at an interior node
 // takes a node step, or every lane at a leaf tests one primitive.  (Letting each lane run to its next leaf and through
 // it keeps a wave waiting for its longest descent: measured lane utilisation 0.33 on bounce rays against 0.52 this way.)
-template <int MODE, bool OVF>
-__device__ __forceinline__ void walk_wave(const DScene& S, Walker<MODE, OVF>& w, bool& alive, LdsStack<OVF>& stk) {
+template <int MODE, bool OVF, class STK>
+__device__ __forceinline__ void walk_wave(const DScene& S, Walker<MODE, OVF>& w, bool& alive, STK& stk) {
 	// (Tried and dropped: letting a lane put the leaf it reaches into a small queue of its own and go on with its stack,
 	// so that primitive steps would find more lanes ready -- primitive steps became more frequent and emptier instead.
 	// Also tried and dropped: setting the last <= 12 walking rays of a batch aside (state and stack to a per-wave slice of
@@ -763,14 +770,12 @@ __device__ __forceinline__ bool item_result(const DScene& S, const DFrame& F, co
 //   results together and receive new rays, so the wave does not idle behind its longest ray.
 // Which one is faster depends on the scene: storing results and setting up rays for a few lanes at a time costs more
 // than it saves while walks are short (Stanford dragon: 7 node steps per ray); with long walks (10 M triangles) it pays.
-#ifndef MIRT_TRACE_ATTR
-#define MIRT_TRACE_ATTR
-#endif
 template <int MODE, bool OVF, bool PRIMARY, bool REFILL>
-__global__ __launch_bounds__(BLOCK) MIRT_TRACE_ATTR void k_trace(DScene S, DFrame F, uint8_t* __restrict__ out, int depth, int launch, int spawn) {
-	__shared__ uint32_t s_stack[STACK_LDS * BLOCK];
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((MODE != MODE_REFWALK && REFILL) ? 6 : 1))) void k_trace(DScene S, DFrame F, uint8_t* __restrict__ out, int depth, int launch, int spawn) {
+	constexpr int NLDS = REFILL ? STACK_LDS_REFILL : STACK_LDS;
+	__shared__ uint32_t s_stack[NLDS * BLOCK];
 	__shared__ uint32_t s_list[BLOCK / WAVE][256];
-	LdsStack<OVF> stk;
+	LdsStack<OVF, NLDS> stk;
 	stk.lds = s_stack + threadIdx.x;
 	stk.ovf = OVF ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
 	stk.ovfStride = S.ovfStride;
