@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <new>
 #include <string>
 #include <vector>
@@ -473,6 +474,15 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	hipDeviceProp_t prop;
 	HIPCHK(hipGetDeviceProperties(&prop, device));
 
+	// MIRT_VERBOSE=1: seconds per phase on stderr
+	const bool verbose = getenv("MIRT_VERBOSE") != nullptr;
+	auto tPhase = std::chrono::steady_clock::now();
+	auto phase = [&](const char* name) {
+		if (!verbose) return;
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "mirt_scene_create: %-28s %.3f s\n", name, std::chrono::duration<double>(now - tPhase).count());
+		tPhase = now;
+	};
 	// primitive id -> triangle index, or -1 - sphere index; objects that are neither never hit (Shape.cpp:44-46)
 	std::vector<int64_t> primSlot(d->n_prims, INT64_MIN);
 	for (uint32_t i = 0; i < d->n_triangles; ++i) primSlot[d->tri_prim[i]] = (int64_t)i;
@@ -511,6 +521,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		if (n.b != MIRT_NO_CHILD && !Packer::inside(d->nodes[n.b], n)) nested = false;
 	}
 
+	phase("membership lists");
 	// ---- primitive hierarchy ---------------------------------------------------------------------------------------------
 	// Bounds are padded so that every point the reference's tests can accept lies inside them: a triangle hit P = o + t*d
 	// sits within ~1e-7 * (|v1| + |o|) of the triangle's plane (rounding of t), a sphere hit within
@@ -565,7 +576,9 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		p.kind = 1;
 		bb.prims.push_back(p);
 	}
+	phase("primitive bounds");
 	bb.run();
+	phase("hierarchy build");
 
 	// primitives in hierarchy order (then the unreferenced ones), per kind
 	std::vector<uint32_t> triNew(d->n_triangles, 0xffffffffu), sphNew(d->n_spheres, 0xffffffffu), triOld, sphOld;
@@ -669,6 +682,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		memcpy(bvhMax, bb.nodes[0].hi, 12);
 	}
 
+	phase("hierarchy collapse + pack");
 	// ---- the reference tree as it is (MODE_REFWALK) ------------------------------------------------------------------------
 	Packer pk;
 	pk.d = d;
@@ -796,6 +810,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	s->nLights = d->n_lights;
 	s->maxDepth = d->max_depth;
 
+	phase("reference tree pack + records");
 	e = upload(s->nodes, pk.wide.data(), pk.wide.size() * 4);
 	if (!e) e = upload(s->leafs, pk.stream.data(), pk.stream.size() * 4);
 	if (!e) e = upload(s->bvh, bvhWide.data(), bvhWide.size() * 4);
@@ -826,6 +841,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		g_err = keep;
 		return e;
 	}
+	phase("upload");
 	ds.nodes = (const float4*)s->nodes.p;
 	ds.leafs = (const uint32_t*)s->leafs.p;
 	ds.bvh = (const float4*)s->bvh.p;

@@ -17,6 +17,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 struct BvhPrim {
@@ -49,6 +51,15 @@ struct BvhBuilder {
 	std::vector<BvhNode> nodes;
 	uint32_t maxDepth = 0;
 
+	// Parallel build: the recursion runs on one thread down to ranges of at most CUT primitives; those ranges are
+	// independent (each works inside its own part of `prims`), so they are built on several threads into node arrays of
+	// their own and spliced in afterwards.  CUT does not depend on the thread count: the tree is the same for any.
+	static const uint32_t CUT = 1u << 16;
+	struct Task { uint32_t start, end, depth; };
+	std::vector<Task> tasks;
+	bool cutting = false;
+	BvhPrim* P = nullptr; // the array build() works on
+
 	static float area(const float* lo, const float* hi) {
 		const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
 		return 2.0f * (dx * dy + dy * dz + dz * dx);
@@ -61,6 +72,10 @@ struct BvhBuilder {
 	}
 
 	int32_t build(uint32_t start, uint32_t end, uint32_t depth) {
+		if (cutting && depth > 0 && end - start <= CUT) {
+			tasks.push_back(Task{start, end, depth});
+			return -2 - (int32_t)(tasks.size() - 1); // placeholder, patched by run()
+		}
 		const int32_t me = (int32_t)nodes.size();
 		nodes.push_back(BvhNode());
 		if (depth > maxDepth) maxDepth = depth;
@@ -68,11 +83,11 @@ struct BvhBuilder {
 		float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
 		bool mixed = false;
 		for (uint32_t i = start; i < end; ++i) {
-			grow(lo, hi, prims[i].lo, prims[i].hi);
+			grow(lo, hi, P[i].lo, P[i].hi);
 			float c[3];
-			for (int k = 0; k < 3; ++k) c[k] = 0.5f * (prims[i].lo[k] + prims[i].hi[k]);
+			for (int k = 0; k < 3; ++k) c[k] = 0.5f * (P[i].lo[k] + P[i].hi[k]);
 			grow(clo, chi, c, c);
-			mixed |= prims[i].kind != prims[start].kind;
+			mixed |= P[i].kind != P[start].kind;
 		}
 		BvhNode n;
 		memcpy(n.lo, lo, 12);
@@ -80,14 +95,14 @@ struct BvhBuilder {
 		n.left = n.right = -1;
 		n.first = start;
 		n.count = end - start;
-		n.kind = prims[start].kind;
+		n.kind = P[start].kind;
 		const uint32_t cnt = end - start;
 		if (cnt <= LEAF_MIN && !mixed) { nodes[me] = n; return me; }
 
 		uint32_t mid = start;
 		if (mixed && cnt <= LEAF_MIN) {
 			// small mixed range: split by kind so that every leaf holds one kind of primitive
-			mid = (uint32_t)(std::partition(prims.begin() + start, prims.begin() + end, [](const BvhPrim& p) { return p.kind == 0; }) - prims.begin());
+			mid = (uint32_t)(std::partition(P + start, P + end, [](const BvhPrim& p) { return p.kind == 0; }) - P);
 		}
 		else {
 			// binned SAH over all three axes; the split must beat the cost of testing the range as one leaf
@@ -106,11 +121,11 @@ struct BvhBuilder {
 					for (int b = 0; b < BINS; ++b) for (int k = 0; k < 3; ++k) { blo[b][k] = INFINITY; bhi[b][k] = -INFINITY; }
 					const float scale = (float)BINS / e;
 					for (uint32_t i = start; i < end; ++i) {
-						const float c = 0.5f * (prims[i].lo[ax] + prims[i].hi[ax]);
+						const float c = 0.5f * (P[i].lo[ax] + P[i].hi[ax]);
 						int b = (int)((c - clo[ax]) * scale);
 						b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
 						bc[b]++;
-						grow(blo[b], bhi[b], prims[i].lo, prims[i].hi);
+						grow(blo[b], bhi[b], P[i].lo, P[i].hi);
 					}
 					float rightArea[BINS];
 					uint32_t rightCnt[BINS];
@@ -140,19 +155,19 @@ struct BvhBuilder {
 					const int ax = bestAxis;
 					const float ca = clo[ax], scale = bestScale;
 					const int bb = bestBin;
-					mid = (uint32_t)(std::partition(prims.begin() + start, prims.begin() + end, [=](const BvhPrim& p) {
+					mid = (uint32_t)(std::partition(P + start, P + end, [=](const BvhPrim& p) {
 						const float c = 0.5f * (p.lo[ax] + p.hi[ax]);
 						int b = (int)((c - ca) * scale);
 						b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
 						return b <= bb;
-					}) - prims.begin());
+					}) - P);
 					done = mid > start && mid < end;
 				}
 			}
 			if (!done) {
 				// balanced median split (also the fallback for coincident centroids)
 				mid = start + cnt / 2;
-				std::nth_element(prims.begin() + start, prims.begin() + mid, prims.begin() + end, [=](const BvhPrim& a, const BvhPrim& b) {
+				std::nth_element(P + start, P + mid, P + end, [=](const BvhPrim& a, const BvhPrim& b) {
 					return (a.lo[axis] + a.hi[axis]) < (b.lo[axis] + b.hi[axis]);
 				});
 			}
@@ -170,10 +185,56 @@ struct BvhBuilder {
 		if (const char* e = getenv("MIRT_BVH_LEAF_MIN")) { const int v = atoi(e); if (v >= 1 && v <= (int)LEAF_CAP) LEAF_MIN = (uint32_t)v; }
 		if (const char* e = getenv("MIRT_BVH_COST_PRIM")) { const float v = (float)atof(e); if (v > 0.0f) COST_PRIM = v; }
 		nodes.clear();
+		tasks.clear();
 		maxDepth = 0;
-		if (!prims.empty()) {
-			nodes.reserve(prims.size());
-			build(0, (uint32_t)prims.size(), 0);
+		if (prims.empty()) return;
+		nodes.reserve(prims.size() / 2);
+		cutting = prims.size() > 4u * CUT;
+		P = prims.data();
+		build(0, (uint32_t)prims.size(), 0);
+		cutting = false;
+		if (tasks.empty()) return;
+		unsigned nThreads = std::thread::hardware_concurrency();
+		if (nThreads > 16) nThreads = 16;
+		if (nThreads < 1) nThreads = 1;
+		if (nThreads > tasks.size()) nThreads = (unsigned)tasks.size();
+		std::vector<std::vector<BvhNode>> sub(tasks.size());
+		std::vector<uint32_t> subDepth(tasks.size(), 0);
+		std::atomic<size_t> next(0);
+		auto work = [&]() {
+			BvhBuilder local; // shares nothing but the primitives of its tasks' ranges
+			local.LEAF_MIN = LEAF_MIN;
+			local.COST_PRIM = COST_PRIM;
+			for (;;) {
+				const size_t t = next.fetch_add(1);
+				if (t >= tasks.size()) break;
+				local.nodes.clear();
+				local.maxDepth = 0;
+				local.P = prims.data(); // ranges of different tasks are disjoint
+				local.build(tasks[t].start, tasks[t].end, tasks[t].depth);
+				sub[t].swap(local.nodes);
+				subDepth[t] = local.maxDepth;
+			}
+		};
+		std::vector<std::thread> th;
+		for (unsigned i = 1; i < nThreads; ++i) th.emplace_back(work);
+		work();
+		for (auto& t : th) t.join();
+		// splice: subtree t's nodes go to the end, its root replaces placeholder -2 - t
+		std::vector<int32_t> rootOf(tasks.size());
+		for (size_t t = 0; t < tasks.size(); ++t) {
+			const int32_t off = (int32_t)nodes.size();
+			rootOf[t] = off;
+			for (BvhNode n : sub[t]) {
+				if (n.left >= 0) { n.left += off; n.right += off; }
+				nodes.push_back(n);
+			}
+			std::vector<BvhNode>().swap(sub[t]);
+			if (subDepth[t] > maxDepth) maxDepth = subDepth[t];
+		}
+		for (BvhNode& n : nodes) {
+			if (n.left <= -2) n.left = rootOf[(size_t)(-2 - n.left)];
+			if (n.right <= -2) n.right = rootOf[(size_t)(-2 - n.right)];
 		}
 	}
 };
