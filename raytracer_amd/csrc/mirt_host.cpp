@@ -155,6 +155,7 @@ struct Prims {
 	std::vector<int64_t> slot;
 	const float* triVerts = nullptr; // 9 per triangle, world space
 	const mirt_sphere* spheres = nullptr;
+	bool allFinite = false; // every triangle coordinate is finite: tri_in_box_finite applies
 };
 
 // Triangle::GetInterval(axis), Triangle.cpp:104-118
@@ -170,14 +171,16 @@ inline void tri_interval(const V3* v, V3 axis, float& lo, float& hi) {
 }
 // Triangle::GetInterval(box, axis), Triangle.cpp:120-145
 inline void box_interval(const Box& b, V3 axis, float& lo, float& hi) {
-	const V3 i = b.lo, a = b.hi;
-	const V3 vertex[8] = { v3(i.x, a.y, a.z), v3(i.x, a.y, i.z), v3(i.x, i.y, a.z), v3(i.x, i.y, i.z),
-		                   v3(a.x, a.y, a.z), v3(a.x, a.y, i.z), v3(a.x, i.y, a.z), v3(a.x, i.y, i.z) };
-	lo = hi = dot(axis, vertex[0]);
+	// the eight corner projections (axis.x*X + axis.y*Y) + axis.z*Z of the reference, with the shared products and
+	// partial sums computed once: every value is produced by the same operations in the same order, so it is identical
+	const float x0 = axis.x * b.lo.x, x1 = axis.x * b.hi.x, y0 = axis.y * b.lo.y, y1 = axis.y * b.hi.y, z0 = axis.z * b.lo.z, z1 = axis.z * b.hi.z;
+	const float s01 = x0 + y1, s00 = x0 + y0, s11 = x1 + y1, s10 = x1 + y0;
+	// corner order of Triangle.cpp:124-133
+	const float p[8] = { s01 + z1, s01 + z0, s00 + z1, s00 + z0, s11 + z1, s11 + z0, s10 + z1, s10 + z0 };
+	lo = hi = p[0];
 	for (int k = 1; k < 8; ++k) {
-		const float p = dot(axis, vertex[k]);
-		lo = (p < lo) ? p : lo;
-		hi = (p > hi) ? p : hi;
+		lo = (p[k] < lo) ? p[k] : lo;
+		hi = (p[k] > hi) ? p[k] : hi;
 	}
 }
 // Triangle::OverlapOnAxis, Triangle.cpp:97-101
@@ -203,6 +206,39 @@ bool tri_in_box(const Box& b, const float* tv) {
 			if (!overlap_on_axis(b, v, cross(us[i], fs[j]))) return false;
 	return true;
 }
+// The same test for finite coordinates.  Ten of the thirteen axes have components that are exactly zero (the box
+// normals, and the cross products of a box normal with an edge); a zero component contributes +-0 to the reference's
+// sums, which changes no value except the sign of a zero, and no comparison.  Dropping those terms leaves every
+// remaining operation as the reference performs it, so every decision is the reference's.
+inline bool overlap2(float lo1, float hi1, float lo2, float hi2, float a1, float a2, float p0a, float p0b, float p1a, float p1b, float p2a, float p2b) {
+	// box: a1*X + a2*Y over the four corners; triangle: a1*v.a + a2*v.b over the three vertices
+	const float x0 = a1 * lo1, x1 = a1 * hi1, y0 = a2 * lo2, y1 = a2 * hi2;
+	const float c0 = x0 + y0, c1 = x0 + y1, c2 = x1 + y0, c3 = x1 + y1;
+	const float alo = fmin2(fmin2(c0, c1), fmin2(c2, c3)), ahi = fmax2(fmax2(c0, c1), fmax2(c2, c3));
+	const float t0 = a1 * p0a + a2 * p0b, t1 = a1 * p1a + a2 * p1b, t2 = a1 * p2a + a2 * p2b;
+	const float blo = fmin2(fmin2(t0, t1), t2), bhi = fmax2(fmax2(t0, t1), t2);
+	return (blo <= ahi) && (alo <= bhi);
+}
+bool tri_in_box_finite(const Box& b, const float* tv) {
+	const V3 v[3] = { v3(tv[0], tv[1], tv[2]), v3(tv[3], tv[4], tv[5]), v3(tv[6], tv[7], tv[8]) };
+	// box normals: the intervals are the coordinate ranges themselves
+	if (!(fmin2(fmin2(v[0].x, v[1].x), v[2].x) <= b.hi.x && b.lo.x <= fmax2(fmax2(v[0].x, v[1].x), v[2].x))) return false;
+	if (!(fmin2(fmin2(v[0].y, v[1].y), v[2].y) <= b.hi.y && b.lo.y <= fmax2(fmax2(v[0].y, v[1].y), v[2].y))) return false;
+	if (!(fmin2(fmin2(v[0].z, v[1].z), v[2].z) <= b.hi.z && b.lo.z <= fmax2(fmax2(v[0].z, v[1].z), v[2].z))) return false;
+	const V3 f0 = sub(v[1], v[0]), f1 = sub(v[2], v[1]), f2 = sub(v[0], v[2]);
+	if (!overlap_on_axis(b, v, cross(f0, f1))) return false;
+	const V3 fs[3] = { f0, f1, f2 };
+	// cross(u0, f) = (0, -f.z, f.y): a1 = -f.z on y, a2 = f.y on z
+	for (int j = 0; j < 3; ++j)
+		if (!overlap2(b.lo.y, b.hi.y, b.lo.z, b.hi.z, -fs[j].z, fs[j].y, v[0].y, v[0].z, v[1].y, v[1].z, v[2].y, v[2].z)) return false;
+	// cross(u1, f) = (f.z, 0, -f.x): a1 = f.z on x, a2 = -f.x on z
+	for (int j = 0; j < 3; ++j)
+		if (!overlap2(b.lo.x, b.hi.x, b.lo.z, b.hi.z, fs[j].z, -fs[j].x, v[0].x, v[0].z, v[1].x, v[1].z, v[2].x, v[2].z)) return false;
+	// cross(u2, f) = (-f.y, f.x, 0): a1 = -f.y on x, a2 = f.x on y
+	for (int j = 0; j < 3; ++j)
+		if (!overlap2(b.lo.x, b.hi.x, b.lo.y, b.hi.y, -fs[j].y, fs[j].x, v[0].x, v[0].y, v[1].x, v[1].y, v[2].x, v[2].y)) return false;
+	return true;
+}
 inline M4 load_m4(const float* p) {
 	M4 r;
 	memcpy(&r, p, sizeof r);
@@ -223,7 +259,7 @@ bool sphere_in_box(const Box& b, const mirt_sphere& s) {
 }
 inline bool box_contains(const Prims& P, const Box& b, uint32_t prim) {
 	const int64_t s = P.slot[prim];
-	if (s >= 0) return tri_in_box(b, P.triVerts + 9 * s);
+	if (s >= 0) return P.allFinite ? tri_in_box_finite(b, P.triVerts + 9 * s) : tri_in_box(b, P.triVerts + 9 * s);
 	if (s == INT64_MIN) return false; // neither triangle nor sphere: Shape::isInside is false (Shape.cpp)
 	return sphere_in_box(b, P.spheres[~s]);
 }
@@ -472,6 +508,8 @@ int build_tree(mirt_host_scene& S, uint32_t threads) {
 	P.spheres = S.spheres.data();
 	for (size_t i = 0; i < S.triPrim.size(); ++i) P.slot[S.triPrim[i]] = (int64_t)i;
 	for (size_t i = 0; i < S.sphPrim.size(); ++i) P.slot[S.sphPrim[i]] = ~(int64_t)i;
+	P.allFinite = true;
+	for (float c : S.triVerts) if (!isfinite(c)) { P.allFinite = false; break; }
 	int nThreads = (int)threads;
 	if (nThreads <= 0) {
 		nThreads = (int)std::thread::hardware_concurrency();
