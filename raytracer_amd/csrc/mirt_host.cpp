@@ -856,6 +856,8 @@ int mirt_host_scene_from_prims(const mirt_scene_desc* d, uint32_t width, uint32_
 		if (d->tri_prim[i] >= d->n_prims) return mirt_set_error(MIRT_E_INVALID, "tri_prim[%u] outside n_prims", i);
 	for (uint32_t i = 0; i < d->n_spheres; ++i)
 		if (d->sphere_prim[i] >= d->n_prims) return mirt_set_error(MIRT_E_INVALID, "sphere_prim[%u] outside n_prims", i);
+	for (uint32_t i = 0; i < d->n_prims; ++i)
+		if (d->prim_material[i] >= d->n_materials) return mirt_set_error(MIRT_E_INVALID, "prim_material[%u] outside n_materials", i);
 	mirt_host_scene* S = nullptr;
 	try {
 		S = new mirt_host_scene();
