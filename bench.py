@@ -163,7 +163,8 @@ def main():
         return {k: {"launches_per_frame": len(v) // nf, "ms_per_frame": sum(v) / nf, "avg_launch_ms": sum(v) / len(v)} for k, v in acc.items()}
 
     # (a) launch durations INSIDE the timed region: the last frame of every stream (frames overlap, so a launch shares the GPU)
-    kern = collect([scene.launch_times(s_.cuda_stream) for s_ in streams[:min(depth, args.steps)]])
+    used = [streams[(frame_no[0] - 1 - i) % depth] for i in range(min(depth, args.steps))]  # streams of the last timed frames
+    kern = collect([scene.launch_times(s_.cuda_stream) for s_ in used])
     # (b) the same launches with nothing else on the GPU, outside the timed region
     kern_alone = collect([(scene.render_device(params, local.data_ptr(), nbytes, stream), scene.launch_times(stream))[1] for _ in range(5)])
     scene.set_profiling(False)
