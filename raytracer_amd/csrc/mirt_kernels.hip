@@ -712,6 +712,8 @@ __device__ __forceinline__ bool item_ray(const DScene& S, const DFrame& F, const
 		return live;
 	}
 	const bool shadow = item < T.nShadowItems;
+	// consecutive shadow items = one hit's queries towards all lights: lanes that share an origin share the first part of
+	// their walks.  (Measured alternative: 64 neighbouring hits towards ONE light per wave -- 4 % slower with 16 lights.)
 	const uint32_t h = shadow ? item / S.nLights : item - T.nShadowItems;
 	const uint32_t slot = T.prevList[h];
 	const float4 ho = F.hitO[T.rd + slot], hd = F.hitD[T.rd + slot];

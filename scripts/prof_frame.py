@@ -13,12 +13,19 @@ from raytracer_amd.scene import FlatScene  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="scene7")
+ap.add_argument("--workload", default=None, help="dragon | cornell | spheres | grid: generated scene text instead of --scene")
 ap.add_argument("--width", type=int, default=3840)
 ap.add_argument("--height", type=int, default=2160)
 ap.add_argument("--mode", type=int, default=0)
 ap.add_argument("--reps", type=int, default=5)
 a = ap.parse_args()
-flat = FlatScene.load(os.path.join(ROOT, "tests", "golden", a.scene + ".flat.npz"))
+if a.workload:
+    from raytracer_amd import workloads  # noqa: E402
+    gen = {"dragon": workloads.dragon, "cornell": workloads.cornell, "spheres": workloads.spheres, "grid": workloads.dragon_grid}
+    flat = FlatScene.from_text(gen[a.workload](a.width, a.height))
+    a.scene = a.workload
+else:
+    flat = FlatScene.load(os.path.join(ROOT, "tests", "golden", a.scene + ".flat.npz"))
 with DeviceScene(flat, 0) as s:
     out = np.zeros((a.height, a.width, 3), np.uint8)
     print(s.query())
@@ -27,7 +34,7 @@ with DeviceScene(flat, 0) as s:
     acc = None
     for _ in range(a.reps):
         _, st = s.render(a.width, a.height, trace_mode=a.mode, out=out)
-        lt = s.launch_times(s_ptr := 0) if False else s.launch_times()
+        lt = s.launch_times()
         acc = [(n, t) for n, t in lt] if acc is None else [(n, t0 + t) for (n, t0), (_, t) in zip(acc, lt)]
     print(a.scene, a.width, a.height, "mode", a.mode, {k: st[k] for k in ("primary_rays", "shadow_rays", "reflection_rays", "primary_hits")})
     tot = 0.0
