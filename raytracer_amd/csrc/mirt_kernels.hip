@@ -326,13 +326,24 @@ __device__ __forceinline__ uint32_t membership(const DScene& S, const RayCtx& r,
 	return REF_NONE;
 }
 
+// Occupancy: the walk is bound by VALU issue and by the latency of its dependent loads, and it gains from every extra
+// resident wave up to 7 per SIMD (Stanford dragon at 3840x2160, Grays/s: 4 waves 7.4, 5: 7.9, 6: 8.5, 7: 8.75, 8: 8.85;
+// 10 M triangles: 6 waves 2.62, 7: 2.72, 8: 2.26 -- at 8 the spills of a 64-register budget cost more than the wave
+// brings).  7 waves per SIMD means 72 VGPRs and, with 7 blocks per CU, 22.5 KB of LDS per block: 18 stack entries per lane
+// next to the wave lists.  The translation unit is compiled without the SLP vectoriser: its packed f32 operations need
+// operands in even-aligned register pairs, and the moves and the wider live ranges that brings cost 35 registers here.
 #ifndef STACK_LDS
-#define STACK_LDS 32
+#define STACK_LDS 18
 #endif
-// The lane-refilling variant of k_trace serves big scenes, where waves wait for memory rather than for the VALU: it is
-// compiled for 6 waves per SIMD (80 VGPRs) and keeps only 20 stack entries per lane in LDS so that 6 blocks fit a CU
-// (10 M triangles: 2.24 -> 2.76 Grays/s against 4 waves; 7 and 8 waves spill too much and lose).
-#define STACK_LDS_REFILL 20
+#ifndef STACK_LDS_REFILL
+#define STACK_LDS_REFILL 18
+#endif
+#ifndef MIRT_BATCH_WAVES
+#define MIRT_BATCH_WAVES 7
+#endif
+#ifndef MIRT_REFILL_WAVES
+#define MIRT_REFILL_WAVES 7
+#endif
 
 // Traversal stack: STACK_LDS entries per lane in LDS ([entry][lane]: conflict-free, no address arithmetic beyond a
 // shift).  Hierarchies deeper than that (OVF = true, chosen by the host from the built depth) keep the deeper entries in
@@ -773,7 +784,7 @@ __device__ __forceinline__ bool item_result(const DScene& S, const DFrame& F, co
 // Which one is faster depends on the scene: storing results and setting up rays for a few lanes at a time costs more
 // than it saves while walks are short (Stanford dragon: 7 node steps per ray); with long walks (10 M triangles) it pays.
 template <int MODE, bool OVF, bool PRIMARY, bool REFILL>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((MODE != MODE_REFWALK && REFILL) ? 6 : 1))) void k_trace(DScene S, DFrame F, uint8_t* __restrict__ out, int depth, int launch, int spawn) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == MODE_REFWALK ? 1 : (REFILL ? MIRT_REFILL_WAVES : MIRT_BATCH_WAVES)))) void k_trace(DScene S, DFrame F, uint8_t* __restrict__ out, int depth, int launch, int spawn) {
 	constexpr int NLDS = REFILL ? STACK_LDS_REFILL : STACK_LDS;
 	__shared__ uint32_t s_stack[NLDS * BLOCK];
 	__shared__ uint32_t s_list[BLOCK / WAVE][256];

@@ -8,7 +8,12 @@ from raytracer_amd.device import DeviceScene
 from raytracer_amd.scene import FlatScene
 name = sys.argv[1] if len(sys.argv) > 1 else "scene7"
 w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
-flat = FlatScene.load(os.path.join(ROOT, "tests", "golden", name + ".flat.npz"))
+if name in ("grid", "spheres", "cornell", "dragon"):  # generated workloads
+    from raytracer_amd import workloads
+    gen = {"dragon": workloads.dragon, "cornell": workloads.cornell, "spheres": workloads.spheres, "grid": workloads.dragon_grid}
+    flat = FlatScene.from_text(gen[name](w, h))
+else:
+    flat = FlatScene.load(os.path.join(ROOT, "tests", "golden", name + ".flat.npz"))
 names = ["node_wave", "node_lane", "prim_wave", "prim_lane", "memb_wave", "memb_lane", "round_wave", "round_lane"]
 def read(s):
     out = {}
