@@ -18,7 +18,11 @@
 
 #pragma clang fp contract(off)
 
-#define GRID_BLOCKS_PER_CU 8
+// blocks per CU in a trace launch = blocks of k_trace that fit a CU at once (7 waves per SIMD): all of them start
+// together and share the work through the launch's cursor
+#ifndef GRID_BLOCKS_PER_CU
+#define GRID_BLOCKS_PER_CU 7
+#endif
 
 namespace {
 
@@ -85,6 +89,52 @@ inline h3 H3(float x, float y, float z) { h3 r = {x, y, z}; return r; }
 inline h3 hsub(h3 a, h3 b) { return H3(a.x - b.x, a.y - b.y, a.z - b.z); }
 inline float hdot(h3 a, h3 b) { float x = a.x * b.x, y = a.y * b.y, z = a.z * b.z; return x + y + z; }
 inline h3 hcross(h3 a, h3 b) { return H3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+
+// Coefficients of tri_hit's filter: out = { v3, E } { a0, c1 } { a1, K } with, for A_i = cross(N, e_i) and
+// C_i = dot(A_i, v3 - v_i'):  a_i = f A_i,  c1 = f C_1,  K = f (C_1 + C_2),  f = sign(area) 2^-g,
+//   2^g >= sum_c |N_c| (|e_a| + |e_b|) for every edge, and >= |N|_1 L;   E = 2^-18 L,  L = largest edge extent;
+// e_i are the reference's float edge vectors and v_i' the vertex its i-th test subtracts (Triangle.cpp:148-150, 163-165).
+// Everything is evaluated in double (products of floats are exact there) and rounded once.  A triangle whose magnitudes
+// could make either evaluation overflow or underflow, or make (s/2)/area underflow for an s the filter calls certain,
+// gets E = NaN: the filter then decides nothing and the reference's operations run.
+inline void tri_filter(float* out, h3 N, h3 v1, h3 v2, h3 v3, float area) {
+	memset(out, 0, 12 * sizeof(float));
+	out[0] = v3.x; out[1] = v3.y; out[2] = v3.z;
+	out[3] = NAN;
+	if (!std::isfinite(area) || area == 0.0f) return;
+	const float all[12] = {N.x, N.y, N.z, v1.x, v1.y, v1.z, v2.x, v2.y, v2.z, v3.x, v3.y, v3.z};
+	for (float f : all) if (!std::isfinite(f) || fabsf(f) > 1e10f) return;
+	const h3 ef[3] = {hsub(v3, v2), hsub(v1, v3), hsub(v2, v1)};
+	const h3 vr[3] = {v3, v1, v2};
+	const double n[3] = {N.x, N.y, N.z};
+	double L = 0.0, top = 0.0;
+	double A[3][3], C[3];
+	for (int i = 0; i < 3; ++i) {
+		const double e[3] = {ef[i].x, ef[i].y, ef[i].z};
+		const double dv[3] = {(double)v3.x - vr[i].x, (double)v3.y - vr[i].y, (double)v3.z - vr[i].z};
+		const double emax = std::max(fabs(e[0]), std::max(fabs(e[1]), fabs(e[2])));
+		if (!(emax >= 1e-12)) return;
+		L = std::max(L, emax);
+		A[i][0] = n[1] * e[2] - e[1] * n[2];
+		A[i][1] = n[2] * e[0] - e[2] * n[0];
+		A[i][2] = n[0] * e[1] - e[0] * n[1];
+		C[i] = A[i][0] * dv[0] + A[i][1] * dv[1] + A[i][2] * dv[2];
+		top = std::max(top, fabs(n[0]) * (fabs(e[1]) + fabs(e[2])) + fabs(n[1]) * (fabs(e[0]) + fabs(e[2])) + fabs(n[2]) * (fabs(e[0]) + fabs(e[1])));
+	}
+	L *= 1.0 + 0x1p-20; // the float edges are rounded differences
+	top = std::max(top, (fabs(n[0]) + fabs(n[1]) + fabs(n[2])) * L);
+	if (!(top > 0.0)) return;
+	int ex = 0;
+	(void)frexp(top, &ex); // top = m 2^ex, m in [0.5, 1): 2^ex > top
+	const double f = ldexp(area > 0.0f ? 1.0 : -1.0, -ex);
+	// a certain sign means |s_i| >= 2^g (1 - 27.2/64) eps >= 2^g 0.5 2^-18 L; (s_i / 2) / area must stay a normal float
+	if (!(ldexp(0.5 * 0x1p-18 * L, ex) / (2.0 * fabs((double)area)) >= 1e-37)) return;
+	float tmp[8] = {(float)(A[0][0] * f), (float)(A[0][1] * f), (float)(A[0][2] * f), (float)(C[1] * f),
+	                (float)(A[1][0] * f), (float)(A[1][1] * f), (float)(A[1][2] * f), (float)((C[1] + C[2]) * f)};
+	for (float t : tmp) if (!std::isfinite(t)) return;
+	memcpy(out + 4, tmp, sizeof tmp);
+	out[3] = (float)(L * 0x1p-18 * (1.0 + 0x1p-20));
+}
 inline h3 hnorm(h3 a) { float s = 1.0f / sqrtf(hdot(a, a)); return H3(a.x * s, a.y * s, a.z * s); }
 
 }  // namespace
@@ -108,7 +158,7 @@ struct mirt_scene {
 	int device = 0;
 	int numCUs = 256;
 	DScene ds;
-	DevBuf nodes, leafs, bvh, memb, tris, triInfo, spheres, sphInfo, materials, lights, ovf, dbg;
+	DevBuf nodes, leafs, bvh, memb, tris, triX, triInfo, spheres, sphInfo, materials, lights, ovf, dbg;
 	bool nested = true;      // reference boxes nested: the primitive hierarchy may be used
 	uint32_t bvhDepth = 0;
 	bool deepBvh = false;    // hierarchy deeper than the LDS part of the traversal stack
@@ -735,8 +785,10 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	memcpy(ds.bvhMin, bvhMin, 12);
 	memcpy(ds.bvhMax, bvhMax, 12);
 
-	// triangles: { N, dot(v1,N) } { v1, area } { v2, 0 } { v3, 0 } in hierarchy order
-	std::vector<float> tris((size_t)d->n_triangles * 16, 0.0f);
+	// triangles in hierarchy order: { N, dot(v1,N) } { v3, E } { a0, c1 } { a1, K } and { v1, area } { v2, 0 }
+	// (E, a_i, c1, K: tri_hit's filter)
+	std::vector<float> tris((size_t)d->n_triangles * TRI_F4 * 4, 0.0f);
+	std::vector<float> triX((size_t)d->n_triangles * 8, 0.0f);
 	std::vector<uint32_t> triInfo((size_t)d->n_triangles * 4, 0);
 	for (uint32_t ni = 0; ni < d->n_triangles; ++ni) {
 		const uint32_t i = triOld[ni];
@@ -746,11 +798,12 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		const float dv = hdot(v1, N);                                // Triangle.cpp:153
 		const h3 e1 = hsub(v3, v2), e2 = hsub(v1, v3);               // Triangle.cpp:148-149
 		const float area = hdot(hcross(e1, e2), N) / 2.0f;           // Triangle.cpp:162
-		float* t = tris.data() + (size_t)ni * 16;
+		float* t = tris.data() + (size_t)ni * TRI_F4 * 4;
 		t[0] = N.x; t[1] = N.y; t[2] = N.z; t[3] = dv;
-		t[4] = v1.x; t[5] = v1.y; t[6] = v1.z; t[7] = area;
-		t[8] = v2.x; t[9] = v2.y; t[10] = v2.z;
-		t[12] = v3.x; t[13] = v3.y; t[14] = v3.z;
+		tri_filter(t + 4, N, v1, v2, v3, area);
+		float* x = triX.data() + (size_t)ni * 8;
+		x[0] = v1.x; x[1] = v1.y; x[2] = v1.z; x[3] = area;
+		x[4] = v2.x; x[5] = v2.y; x[6] = v2.z;
 		const uint32_t prim = d->tri_prim[i];
 		uint32_t* inf = triInfo.data() + (size_t)ni * 4;
 		inf[0] = prim; inf[1] = d->prim_material[prim]; inf[2] = mOfs[prim]; inf[3] = mCnt[prim];
@@ -816,6 +869,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	if (!e) e = upload(s->bvh, bvhWide.data(), bvhWide.size() * 4);
 	if (!e) e = upload(s->memb, memb.data(), memb.size() * 4);
 	if (!e) e = upload(s->tris, tris.data(), tris.size() * 4);
+	if (!e) e = upload(s->triX, triX.data(), triX.size() * 4);
 	if (!e) e = upload(s->triInfo, triInfo.data(), triInfo.size() * 4);
 	if (!e) e = upload(s->spheres, sph.data(), sph.size() * 4);
 	if (!e) e = upload(s->sphInfo, sphInfo.data(), sphInfo.size() * 4);
@@ -847,6 +901,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	ds.bvh = (const float4*)s->bvh.p;
 	ds.memb = (const float4*)s->memb.p;
 	ds.tris = (const float4*)s->tris.p;
+	ds.triX = (const float4*)s->triX.p;
 	ds.triInfo = (const uint4*)s->triInfo.p;
 	ds.spheres = (const float4*)s->spheres.p;
 	ds.sphInfo = (const uint4*)s->sphInfo.p;
@@ -860,7 +915,7 @@ void mirt_scene_destroy(mirt_scene* s) {
 	if (!s) return;
 	(void)hipSetDevice(s->device);
 	if (s->stream) (void)hipStreamSynchronize(s->stream);
-	s->nodes.release(); s->leafs.release(); s->bvh.release(); s->memb.release(); s->tris.release(); s->triInfo.release();
+	s->nodes.release(); s->leafs.release(); s->bvh.release(); s->memb.release(); s->tris.release(); s->triX.release(); s->triInfo.release();
 	s->spheres.release(); s->sphInfo.release(); s->materials.release(); s->lights.release(); s->ovf.release(); s->dbg.release();
 	for (FrameCtx* c : s->ctxs) {
 		(void)hipStreamSynchronize(c->stream);
@@ -897,12 +952,23 @@ int mirt_scene_query(mirt_scene* s, uint32_t what, uint64_t* v) {
 	case MIRT_Q_TREE_NESTED: *v = s->nested ? 1 : 0; break;
 	case MIRT_Q_MEMBERSHIP_ENTRIES: *v = s->memb.bytes / 32; break;
 	case MIRT_Q_DEVICE_BYTES:
-		*v = s->nodes.bytes + s->leafs.bytes + s->bvh.bytes + s->memb.bytes + s->tris.bytes + s->triInfo.bytes + s->spheres.bytes + s->sphInfo.bytes +
+		*v = s->nodes.bytes + s->leafs.bytes + s->bvh.bytes + s->memb.bytes + s->tris.bytes + s->triX.bytes + s->triInfo.bytes + s->spheres.bytes + s->sphInfo.bytes +
 		     s->materials.bytes + s->lights.bytes + s->ovf.bytes;
 		break;
 	case MIRT_Q_TREE_WIDE_DEPTH: *v = s->wideDepth; break;
 	default:
 		if (what >= 120 && what < 128) { *v = s->diag[what - 120]; break; }
+#if MIRT_STATS
+		if (what == 116) { // triangle tests that fell back from the filter to the reference's operations (read and clear)
+			unsigned long long x = 0, z = 0;
+			HIPCHK(hipSetDevice(s->device));
+			HIPCHK(hipDeviceSynchronize());
+			HIPCHK(hipMemcpyFromSymbol(&x, HIP_SYMBOL(g_statFallback), 8));
+			HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_statFallback), &z, 8));
+			*v = x;
+			break;
+		}
+#endif
 		if (what >= 100 && what < 116) { // diagnostic event counters of MIRT_STATS builds (read and clear)
 			unsigned long long x = 0;
 			HIPCHK(hipSetDevice(s->device));

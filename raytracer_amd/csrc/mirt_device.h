@@ -48,6 +48,7 @@
 #define MIRT_MAX_DEPTH_LIMIT 30
 
 #define SPHERE_F4 9
+#define TRI_F4 4
 
 struct DCamera {
 	float eye[3], u[3], v[3], w[3];
@@ -57,7 +58,8 @@ struct DCamera {
 struct DScene {
 	// (1) primitive hierarchy
 	const float4* bvh;
-	const float4* tris;
+	const float4* tris;   // TRI_F4 per triangle: plane, v3 and the filter's edge functions (tri_hit)
+	const float4* triX;   // 2 per triangle: v1, area, v2 -- the rest of what the reference's own inside test reads
 	const uint4* triInfo;
 	const float4* spheres;
 	const uint4* sphInfo;

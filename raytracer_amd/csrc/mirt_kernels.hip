@@ -75,7 +75,6 @@ struct Hit {
 
 struct RayCtx {
 	f3 o, d;
-	f3 e;      // direction with AABB.cpp:53-58's substitution: |d| < 1e-5 -> +1e-5
 	f3 ie;     // 1/d for the hierarchy's conservative box filter
 	f3 oie;    // o * ie
 	float invLen; // 1/|d|, used only for conservative culling
@@ -85,9 +84,6 @@ __device__ __forceinline__ RayCtx make_ray(f3 o, f3 d) {
 	RayCtx r;
 	r.o = o;
 	r.d = d;
-	r.e.x = (fabsf(d.x - 0.0f) < 0.00001f) ? 0.00001f : d.x;
-	r.e.y = (fabsf(d.y - 0.0f) < 0.00001f) ? 0.00001f : d.y;
-	r.e.z = (fabsf(d.z - 0.0f) < 0.00001f) ? 0.00001f : d.z;
 	// reciprocal of the TRUE direction for the hierarchy's conservative filter (tiny components clamped, sign kept)
 	const float sx = fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x;
 	const float sy = fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y;
@@ -99,17 +95,24 @@ __device__ __forceinline__ RayCtx make_ray(f3 o, f3 d) {
 	return r;
 }
 
-// AABB::intersect hit/miss (AABB.cpp:53-72).  tnear receives tmin (ray-parameter units).
+// The direction with AABB.cpp:53-58's substitution: |d| < 1e-5 -> +1e-5.  Not kept in RayCtx: only the reference's own
+// box test needs it, and three registers held through the whole walk cost more than recomputing it there.
+__device__ __forceinline__ f3 box_dir(const RayCtx& r) {
+	return F3((fabsf(r.d.x - 0.0f) < 0.00001f) ? 0.00001f : r.d.x, (fabsf(r.d.y - 0.0f) < 0.00001f) ? 0.00001f : r.d.y,
+	          (fabsf(r.d.z - 0.0f) < 0.00001f) ? 0.00001f : r.d.z);
+}
+
+// AABB::intersect hit/miss (AABB.cpp:53-72), e = box_dir(r).  tnear receives tmin (ray-parameter units).
 template <int MODE>
-__device__ __forceinline__ bool box_hit(const RayCtx& r, f3 lo, f3 hi, float& tnear) {
+__device__ __forceinline__ bool box_hit(const RayCtx& r, const f3& e, f3 lo, f3 hi, float& tnear) {
 	float t1, t2, t3, t4, t5, t6;
 	if (MODE == MODE_EXACT) {
-		t1 = (lo.x - r.o.x) / r.e.x;
-		t2 = (hi.x - r.o.x) / r.e.x;
-		t3 = (lo.y - r.o.y) / r.e.y;
-		t4 = (hi.y - r.o.y) / r.e.y;
-		t5 = (lo.z - r.o.z) / r.e.z;
-		t6 = (hi.z - r.o.z) / r.e.z;
+		t1 = (lo.x - r.o.x) / e.x;
+		t2 = (hi.x - r.o.x) / e.x;
+		t3 = (lo.y - r.o.y) / e.y;
+		t4 = (hi.y - r.o.y) / e.y;
+		t5 = (lo.z - r.o.z) / e.z;
+		t6 = (hi.z - r.o.z) / e.z;
 	}
 	else {
 		t1 = (lo.x - r.o.x) * r.ie.x;
@@ -130,10 +133,29 @@ __device__ __forceinline__ bool box_hit(const RayCtx& r, f3 lo, f3 hi, float& tn
 	return true;
 }
 
-// Triangle::intersect (Triangle.cpp:147-175) on the precomputed record.  Returns the hit distance or -1.
+// Triangle::intersect (Triangle.cpp:147-175) on the precomputed records.  Returns the hit distance or -1.
 // tcull: ray-parameter bound beyond which a hit cannot matter (conservative, see traverse()).
+//
+// T = { N, dot(v1,N) } { v3, E } { a0, c1 } { a1, K },  X = { v1, area } { v2, 0 }.
+// The reference decides "inside" from the signs of s_i = dot(cross(e_i, P - v_i'), N) against the sign of the area
+// (:163-166), about fifty dependent operations.  By the triple-product identity s_i = dot(A_i, P - v_i') with
+// A_i = cross(N, e_i), an affine function of q = P - v3; and because the edges add up to (almost) zero,
+// s_2 = C_1 + C_2 - s_0 - s_1 + dot(cross(N, e_1 + e_2 + e_3), q) with C_i = dot(A_i, v3 - v_i').  The host evaluates
+// A_0, A_1, C_1, C_1 + C_2 in double, multiplies them by sign(area) 2^-g, where 2^g bounds G_i = sum_c |N_c| (|e_a| + |e_b|)
+// of every edge and |N|_1 L (L = the triangle's largest edge extent), and rounds to float: a0, a1, c1, K.  Then
+//   s~0 = a0.q,  s~1 = a1.q + c1  (FMA chains),  s~2 = (K - s~0) - s~1,
+// and, with u = 2^-24, |s~_i - sign(area) 2^-g s_i| <= 27.2 u (|q|_inf + L) for every i: the reference's own evaluation is
+// within 6 u G_i (|q|_inf + L) of the real value (six roundings per term); a chain is within 5.02 u |q|_inf resp.
+// 6.03 u (|q|_inf + L) (2 u per product, 1 u for c1, three chain roundings); K adds 2.02 u L, the two subtractions
+// 6 u L + 4 u |q|_inf, and the neglected edge-sum term is below 6 u |q|_inf (|e_1 + e_2 + e_3|_inf <= 3 u L).
+// With eps = 2^-18 (|q|_1 + L) = 64 u (...) (E holds 2^-18 L) the sign of s_i is certain when |s~_i| > eps, which leaves a
+// ~1e-5 fraction of the tests undecided; those, and every triangle or point whose magnitudes leave room for overflow or
+// underflow in either evaluation (host: E = NaN; here: |q|_1 >= 1e10), run the reference's operations as they stand.
+#if MIRT_STATS
+__device__ unsigned long long g_statFallback[1];
+#endif
 template <int MODE>
-__device__ __forceinline__ float tri_hit(const RayCtx& r, const float4* __restrict__ T, float tcull) {
+__device__ __forceinline__ float tri_hit(const RayCtx& r, const float4* __restrict__ T, const float4* __restrict__ X, float tcull) {
 	const float4 q0 = T[0];
 	const f3 N = F3(q0);
 	const float dn = dot3(r.d, N);
@@ -141,22 +163,39 @@ __device__ __forceinline__ float tri_hit(const RayCtx& r, const float4* __restri
 	const float t = (q0.w - dot3(r.o, N)) / dn;               // :153-154
 	if (t < 0.0001f) return -1.0f;                            // :155
 	if (t > tcull) return -1.0f;                              // cannot beat the current best
-	const float4 q1 = T[1], q2 = T[2], q3 = T[3];
-	const f3 v1 = F3(q1), v2 = F3(q2), v3 = F3(q3);
-	const float area = q1.w;                                  // :162, evaluated on the host
-	const f3 e1 = v3 - v2, e2 = v1 - v3, e3 = v2 - v1;        // :148-150
+	const float4 k0 = T[1], k1 = T[2], k2 = T[3];
+	const f3 v3 = F3(k0);
 	const f3 P = r.o + r.d * t;                               // :158
-	const float s0 = dot3(cross3(e1, P - v3), N);             // :163
-	const float s1 = dot3(cross3(e2, P - v1), N);             // :164
-	const float s2 = dot3(cross3(e3, P - v2), N);             // :165
+	const f3 q = P - v3;                                      // the first operand of :163 as well
+	const float s0f = __builtin_fmaf(k1.z, q.z, __builtin_fmaf(k1.y, q.y, k1.x * q.x));
+	const float s1f = __builtin_fmaf(k2.z, q.z, __builtin_fmaf(k2.y, q.y, __builtin_fmaf(k2.x, q.x, k1.w)));
+	const float s2f = (k2.w - s0f) - s1f;
+	const float m = (fabsf(q.x) + fabsf(q.y)) + fabsf(q.z);  // NaN propagates into eps and fails both comparisons
+	const float eps = __builtin_fmaf(m, 0x1p-18f, k0.w);
+	const float lof = fminf(fminf(s0f, s1f), s2f);
+	const bool sane = m < 1e10f;
 	bool in;
-	// (s/2)/area >= 0 is decided by the signs alone unless the quotient can underflow or overflow
-	const float lo = fminf(fminf(fabsf(s0), fabsf(s1)), fabsf(s2));
-	if (MODE == MODE_FAST || (fabsf(area) < 1e30f && (lo > 1e-30f))) {
-		in = (s0 * area >= 0.0f) && (s1 * area >= 0.0f) && (s2 * area >= 0.0f);
-	}
+	if (sane && lof > eps) in = true;
+	else if (sane && lof < -eps) in = false;
 	else {
-		in = (s0 / 2.0f / area >= 0.0f) && (s1 / 2.0f / area >= 0.0f) && (s2 / 2.0f / area >= 0.0f);
+#if MIRT_STATS
+		atomicAdd(g_statFallback, 1ull);
+#endif
+		const float4 q1 = X[0], q2 = X[1];
+		const f3 v1 = F3(q1), v2 = F3(q2);
+		const float area = q1.w;                                  // :162, evaluated on the host
+		const f3 e1 = v3 - v2, e2 = v1 - v3, e3 = v2 - v1;        // :148-150
+		const float s0 = dot3(cross3(e1, q), N);                  // :163
+		const float s1 = dot3(cross3(e2, P - v1), N);             // :164
+		const float s2 = dot3(cross3(e3, P - v2), N);             // :165
+		// (s/2)/area >= 0 is decided by the signs alone unless the quotient can underflow (to a zero that compares >= 0)
+		const float lo = fminf(fminf(fabsf(s0), fabsf(s1)), fabsf(s2));
+		if (MODE == MODE_FAST || (fabsf(area) < 1e7f && fabsf(area) > 1e-30f && lo > 1e-30f)) {
+			in = area > 0.0f ? (s0 >= 0.0f && s1 >= 0.0f && s2 >= 0.0f) : (s0 <= 0.0f && s1 <= 0.0f && s2 <= 0.0f);
+		}
+		else {
+			in = (s0 / 2.0f / area >= 0.0f) && (s1 / 2.0f / area >= 0.0f) && (s2 / 2.0f / area >= 0.0f);
+		}
 	}
 	if (!in) return -1.0f;
 	return length3(r.o - P);                                   // :167 glm::distance(P, origin)
@@ -238,7 +277,8 @@ __device__ __noinline__ bool traverse_ref(const DScene& S, const RayCtx& r, floa
 	best.pos = 0xffffffffu;
 	float tcull = (ANY && S.refCull) ? (limit * r.invLen * 1.0001f + 1e-5f) : __builtin_inff();
 	float tn;
-	if (S.rootRef == REF_NONE || !box_hit<MODE_EXACT>(r, F3(S.rootMin), F3(S.rootMax), tn)) return false; // Partition.cpp:36 on the root
+	const f3 e = box_dir(r);
+	if (S.rootRef == REF_NONE || !box_hit<MODE_EXACT>(r, e, F3(S.rootMin), F3(S.rootMax), tn)) return false; // Partition.cpp:36 on the root
 	uint32_t stkRef[STACK_MAX];
 	float stkT[STACK_MAX];
 	int sp = 0;
@@ -249,8 +289,8 @@ __device__ __noinline__ bool traverse_ref(const DScene& S, const RayCtx& r, floa
 			const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
 			const uint32_t lref = __float_as_uint(q0.w), rref = __float_as_uint(q1.w);
 			float tl, tr;
-			const bool hl = (lref != REF_NONE) && box_hit<MODE_EXACT>(r, F3(q0), F3(q1), tl) && !(tl > tcull);
-			const bool hr = (rref != REF_NONE) && box_hit<MODE_EXACT>(r, F3(q2), F3(q3), tr) && !(tr > tcull);
+			const bool hl = (lref != REF_NONE) && box_hit<MODE_EXACT>(r, e, F3(q0), F3(q1), tl) && !(tl > tcull);
+			const bool hr = (rref != REF_NONE) && box_hit<MODE_EXACT>(r, e, F3(q2), F3(q3), tr) && !(tr > tcull);
 			if (hl && hr) {
 				const bool leftFirst = tl <= tr;
 				stkRef[sp] = leftFirst ? rref : lref;
@@ -274,7 +314,7 @@ __device__ __noinline__ bool traverse_ref(const DScene& S, const RayCtx& r, floa
 					dist = sphere_hit<false>(r, S.spheres + (size_t)(pr & ~PRIM_SPHERE) * SPHERE_F4, dummy);
 				}
 				else {
-					dist = tri_hit<MODE_EXACT>(r, S.tris + (size_t)pr * 4, tcull);
+					dist = tri_hit<MODE_EXACT>(r, S.tris + (size_t)pr * TRI_F4, S.triX + (size_t)pr * 2, tcull);
 				}
 				if (dist >= 0.0f && !isinf(dist)) {
 					if (ANY) {
@@ -317,11 +357,12 @@ __device__ __forceinline__ bool box_filter(const RayCtx& r, const float4& lo, co
 // Is the primitive held by a reference leaf whose box the ray hits?  Returns the visiting rank of the first such
 // (leaf, primitive) entry, or REF_NONE.  AABB::intersect is evaluated exactly (IEEE division, AABB.cpp:53-72).
 __device__ __forceinline__ uint32_t membership(const DScene& S, const RayCtx& r, uint32_t ofs, uint32_t cnt) {
-	const float4* e = S.memb + (size_t)ofs * 2;
+	const float4* m = S.memb + (size_t)ofs * 2;
+	const f3 e = box_dir(r);
 	for (uint32_t k = 0; k < cnt; ++k) {
-		const float4 lo = e[2 * k], hi = e[2 * k + 1];
+		const float4 lo = m[2 * k], hi = m[2 * k + 1];
 		float tn;
-		if (box_hit<MODE_EXACT>(r, F3(lo), F3(hi), tn)) return __float_as_uint(lo.w);
+		if (box_hit<MODE_EXACT>(r, e, F3(lo), F3(hi), tn)) return __float_as_uint(lo.w);
 	}
 	return REF_NONE;
 }
@@ -475,7 +516,7 @@ struct Walker {
 			dist = sphere_hit<false>(r, S.spheres + (size_t)idx * SPHERE_F4, dummy);
 		}
 		else {
-			dist = tri_hit<MODE>(r, S.tris + (size_t)idx * 4, tcull);
+			dist = tri_hit<MODE>(r, S.tris + (size_t)idx * TRI_F4, S.triX + (size_t)idx * 2, tcull);
 		}
 		if (!(dist >= 0.0f) || isinf(dist)) return false;
 		const uint32_t ref = sph ? (PRIM_SPHERE | idx) : idx;
@@ -575,7 +616,7 @@ __device__ __forceinline__ f3 hit_normal(const DScene& S, const RayCtx& r, uint3
 		sphere_hit<true>(r, S.spheres + (size_t)(ref & ~PRIM_SPHERE) * SPHERE_F4, n);
 		return normalize3(n);
 	}
-	return normalize3(F3(S.tris[(size_t)ref * 4]));
+	return normalize3(F3(S.tris[(size_t)ref * TRI_F4]));
 }
 __device__ __forceinline__ uint4 info_of(const DScene& S, uint32_t ref) {
 	return (ref & PRIM_SPHERE) ? S.sphInfo[ref & ~PRIM_SPHERE] : S.triInfo[ref];

@@ -30,5 +30,8 @@ with DeviceScene(flat, 0) as s:
         rays = st["primary_rays"] + (st["shadow_rays_traced"] + st["reflection_rays"] if feats == 15 else 0)
         print(label, st)
         print("  per ray: node steps %.1f, prim tests %.1f, membership %.2f, rounds %.1f" % (c["node_lane"] / rays, c["prim_lane"] / rays, c["memb_lane"] / rays, c["round_lane"] / rays))
+        fb = C.c_uint64()
+        if s.lib.mirt_scene_query(s.h, 116, C.byref(fb)) == 0:
+            print("  triangle filter fallbacks: %d (%.2e of primitive tests)" % (fb.value, fb.value / max(1, c["prim_lane"])))
         for k in ("node", "prim", "memb", "round"):
             print("  %-6s lane utilisation %.2f  (wave iterations %d)" % (k, c[k + "_lane"] / max(1, 64 * c[k + "_wave"]), c[k + "_wave"]))
