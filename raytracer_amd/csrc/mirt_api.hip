@@ -696,7 +696,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 					scale[k] = ldexpf(1.0f, biased - 127);
 					memcpy(&w[k], &nd.lo[k], 4);
 				}
-				w[3] = ex[0] | (ex[1] << 8) | (ex[2] << 16);
+				w[3] = ((ex[0] - 127u) & 0xffu) | (((ex[1] - 127u) & 0xffu) << 8) | (((ex[2] - 127u) & 0xffu) << 16); // signed bytes
 				uint32_t refs[4] = { BVH_DONE, BVH_DONE, BVH_DONE, BVH_DONE };
 				for (int c = 0; c < 4; ++c) {
 					uint32_t qlo[3] = {255, 255, 255}, qhi[3] = {0, 0, 0};

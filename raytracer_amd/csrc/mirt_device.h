@@ -6,7 +6,7 @@
 //     (mirt_bvh.h) and collapsed to four children per node.  It is a conservative FILTER: it only decides which
 //     primitives are tested at all.  The tracing kernels are limited by the number of 16-byte loads a lane issues
 //     (the L1 data path serves about one diverging lane per cycle), so a node is 64 B for FOUR child boxes:
-//       q0 = { origin.xyz (float), ex | ey << 8 | ez << 16 }     scale_k = 2^(e_k - 127)
+//       q0 = { origin.xyz (float), ex | ey << 8 | ez << 16 }     signed bytes: scale_k = 2^e_k
 //       q1 = { lo.x[4], lo.y[4], lo.z[4], hi.x[4] }              one byte per child: bound = origin_k + byte * scale_k,
 //       q2 = { hi.y[4], hi.z[4], ref0, ref1 }                    lower bounds rounded down, upper bounds rounded up
 //       q3 = { ref2, ref3, 0, 0 }
@@ -25,7 +25,8 @@
 //     walked exhaustively-equivalent by MODE_REFWALK.  Used as the fallback when the handed-over tree's boxes are
 //     not nested, and by tests to cross-check (1)+(2) at full image sizes.
 //
-//   triangle, 64 B = 4 x float4:  { N.xyz, dot(v1,N) } { v1.xyz, area } { v2.xyz, 0 } { v3.xyz, 0 }
+//   triangle, 64 B = 4 x float4:  { N.xyz, dot(v1,N) } { v3.xyz, E } { a0.xyz, c1 } { a1.xyz, K }   (tri_hit's filter)
+//             + 32 B = 2 x float4:  { v1.xyz, area } { v2.xyz, 0 }   read only when the filter is undecided
 //     N = normalize(cross(v2-v1, v3-v1)), dot(v1,N) and area = dot(cross(e1,e2),N)/2 are evaluated on the host with
 //     exactly the operations Triangle::intersect performs per call (Triangle.cpp:151-153,162), so loading them
 //     is bit-identical to recomputing them.

@@ -463,14 +463,23 @@ struct Walker {
 		STAT_LANE(S, 1); // node steps (lanes)
 		const uint4* nd = (const uint4*)S.bvh + (size_t)cur * 4;
 		const uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-		const float ax = __uint_as_float((q0.w & 0xffu) << 23) * r.ie.x;
-		const float ay = __uint_as_float(((q0.w >> 8) & 0xffu) << 23) * r.ie.y;
-		const float az = __uint_as_float(((q0.w >> 16) & 0xffu) << 23) * r.ie.z;
+		// scale/d per axis: the node stores signed power-of-two exponents
+		const float ax = __builtin_ldexpf(r.ie.x, (int)(q0.w << 24) >> 24);
+		const float ay = __builtin_ldexpf(r.ie.y, (int)(q0.w << 16) >> 24);
+		const float az = __builtin_ldexpf(r.ie.z, (int)(q0.w << 8) >> 24);
 		const float bx = __builtin_fmaf(__uint_as_float(q0.x), r.ie.x, -r.oie.x);
 		const float by = __builtin_fmaf(__uint_as_float(q0.y), r.ie.y, -r.oie.y);
 		const float bz = __builtin_fmaf(__uint_as_float(q0.z), r.ie.z, -r.oie.z);
 		uint32_t key[4], ref[4];
 		ref[0] = q2.z; ref[1] = q2.w; ref[2] = q3.x; ref[3] = q3.y;
+		// Which plane of an axis the ray meets first depends on the sign of its direction only (t = q * a + b is monotone
+		// in q), so the four children's near planes are picked once per node, a whole word of bytes at a time, instead of
+		// taking min and max of every pair of parameters.
+		const uint32_t mx = (uint32_t)((int)__float_as_uint(r.ie.x) >> 31), my = (uint32_t)((int)__float_as_uint(r.ie.y) >> 31),
+		               mz = (uint32_t)((int)__float_as_uint(r.ie.z) >> 31); // all ones: the ray goes down the axis
+		const uint32_t nearX = (mx & q1.w) | (~mx & q1.x), farX = (mx & q1.x) | (~mx & q1.w);
+		const uint32_t nearY = (my & q2.x) | (~my & q1.y), farY = (my & q1.y) | (~my & q2.x);
+		const uint32_t nearZ = (mz & q2.y) | (~mz & q1.z), farZ = (mz & q1.z) | (~mz & q2.y);
 		typedef float pk2 __attribute__((ext_vector_type(2))); // both planes of an axis in one packed FMA
 		const pk2 pax = {ax, ax}, pay = {ay, ay}, paz = {az, az}, pbx = {bx, bx}, pby = {by, by}, pbz = {bz, bz};
 		// entry no earlier than the ray's start, exit no later than the culling bound (which is never negative):
@@ -478,12 +487,12 @@ struct Walker {
 #pragma unroll
 		for (int c = 0; c < 4; ++c) {
 			const int sh = 8 * c;
-			const pk2 qx = {(float)((q1.x >> sh) & 0xffu), (float)((q1.w >> sh) & 0xffu)};
-			const pk2 qy = {(float)((q1.y >> sh) & 0xffu), (float)((q2.x >> sh) & 0xffu)};
-			const pk2 qz = {(float)((q1.z >> sh) & 0xffu), (float)((q2.y >> sh) & 0xffu)};
+			const pk2 qx = {(float)((nearX >> sh) & 0xffu), (float)((farX >> sh) & 0xffu)};
+			const pk2 qy = {(float)((nearY >> sh) & 0xffu), (float)((farY >> sh) & 0xffu)};
+			const pk2 qz = {(float)((nearZ >> sh) & 0xffu), (float)((farZ >> sh) & 0xffu)};
 			const pk2 tx = __builtin_elementwise_fma(qx, pax, pbx), ty = __builtin_elementwise_fma(qy, pay, pby), tz = __builtin_elementwise_fma(qz, paz, pbz);
-			const float tmin = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), 0.0f));
-			const float tmax = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), tcull));
+			const float tmin = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, 0.0f));
+			const float tmax = fminf(fminf(tx.y, ty.y), fminf(tz.y, tcull));
 			const bool hit = (tmin <= tmax) && ref[c] != BVH_DONE;
 			// non-negative floats order like their bit patterns
 			key[c] = hit ? __float_as_uint(tmin) : 0xffffffffu;
