@@ -778,7 +778,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	s->wideDepth = pk.maxDepth;
 	s->bvhDepth = bvhWideDepth;
 	// Long walks (big scenes) make refilling idle lanes pay; short ones do not (see k_trace).  MIRT_REFILL_MIN overrides.
-	s->refillMin = bvhWide.size() / 16 > 500000u ? 48u : 64u;
+	s->refillMin = bvhWide.size() / 16 > 500000u ? 36u : 64u;
 	if (const char* env = getenv("MIRT_REFILL_MIN")) { const int v = atoi(env); if (v >= 1 && v <= 64) s->refillMin = (uint32_t)v; }
 	memcpy(s->diag, bvhDiag, sizeof bvhDiag);
 	ds.bvhRoot = bvhRoot;

@@ -897,7 +897,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == M
 		}
 		else {
 			const int nDead = __popcll(__ballot(!alive));
-			if (!(sup.exhausted() ? (nDead == 64 || __ballot(parked) != 0ull) : nDead >= (int)F.refillMin)) {
+			if (!(sup.exhausted() ? nDead == 64 : nDead >= (int)F.refillMin)) { // nothing left to hand out: finish the last rays together
 				// One step for the whole wave: the larger (weighted) group of lanes goes, see walk_wave
 				const bool wantNode = alive && w.at_node();
 				const bool wantLeaf = alive && !wantNode;
