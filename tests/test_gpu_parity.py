@@ -60,6 +60,24 @@ def test_render_exact_all_feature_combos(name, features, dev_scenes, goldens):
     assert [st["primary_rays"], st["shadow_rays"], st["reflection_rays"]] == g["rays_f%d" % features].tolist()
 
 
+@pytest.mark.parametrize("refill_min", [8, 40])
+@pytest.mark.parametrize("name", ["scene5", "scene6", "scene7"])
+def test_lane_refilling_variant_exact(name, refill_min, flat_scenes, goldens, monkeypatch):
+    """The library picks the lane-refilling kernel variant for big scenes only; MIRT_REFILL_MIN forces it (lanes are
+    refilled once that many are idle), so the small scenes cover it too: all features and two debug views."""
+    from raytracer_amd.device import DeviceScene
+    monkeypatch.setenv("MIRT_REFILL_MIN", str(refill_min))
+    g = goldens(name)
+    w, h = int(g["width"]), int(g["height"])
+    with DeviceScene(flat_scenes(name), 0) as s:
+        img, st = s.render(w, h, features=15)
+        assert np.array_equal(img, g["bgr_f15"])
+        assert [st["primary_rays"], st["shadow_rays"], st["reflection_rays"]] == g["rays_f15"].tolist()
+        for debug in (_capi.DEBUG_SHADOW_MAP, _capi.DEBUG_PRIMARY_MAP):
+            img, _ = s.render(w, h, debug=debug)
+            assert np.array_equal(img, g["bgr_debug%d" % debug])
+
+
 @pytest.mark.parametrize("name", ["scene1", "scene5", "scene6", "scene7"])
 @pytest.mark.parametrize("debug", range(_capi.DEBUG_NONE))
 def test_render_exact_debug_views(name, debug, dev_scenes, goldens):
