@@ -728,17 +728,20 @@ __device__ __forceinline__ void walk_wave(const DScene& S, Walker<MODE, OVF>& w,
 	// global memory) and resuming them 64 at a time at the end of the launch.  On the Stanford dragon 40 % of all lane
 	// slots belong to rays that are already finished, but the number of walking lanes decays gradually rather than
 	// leaving a few stragglers: the wave iterations fell by 7 % only, which the extra registers ate.)
+	// A lane without a walk holds cur == BVH_DONE, so both questions are single signed comparisons of cur (node references
+	// are non-negative, leaf references lie below -1) and the ballots come straight from the compare unit.
+	if (!alive) w.cur = BVH_DONE;
 	for (;;) {
-		const bool wantNode = alive && w.at_node();
-		const bool wantLeaf = alive && !wantNode;
-		const int nNode = __popcll(__ballot(wantNode)), nLeaf = __popcll(__ballot(wantLeaf));
+		const int c = (int)w.cur;
+		const bool wantNode = c >= 0, wantLeaf = c < -1;
+		const int nNode = __popcll(__builtin_amdgcn_ballot_w64(wantNode)), nLeaf = __popcll(__builtin_amdgcn_ballot_w64(wantLeaf));
 		if (nNode + nLeaf == 0) break;
 		if (nNode * MIRT_NODE_WEIGHT >= nLeaf * MIRT_LEAF_WEIGHT) {
 			if (wantNode) w.node_step(S, stk);
 		}
 		else if (wantLeaf) w.leaf_step(S, stk);
-		alive = alive && w.cur != BVH_DONE;
 	}
+	alive = false;
 }
 
 // ---- the tracing kernel: every ray of one depth in one launch ---------------------------------------------------------------
@@ -862,6 +865,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == M
 	uint32_t tag = 0;
 	bool alive = false;
 	bool parked = false; // the lane holds a finished ray whose result is not stored yet
+	w.cur = BVH_DONE;    // no walk yet
 	for (;;) {
 		if (!REFILL) {
 			uint32_t base = 0;
@@ -888,7 +892,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == M
 				// deferred check of the final answers; the rare ray that fails it is walked again, strictly
 				if (MODE == MODE_EXACT) {
 					const bool redo = parked && !w.verify(S);
-					if (__ballot(redo)) {
+					if (__builtin_amdgcn_ballot_w64(redo)) {
 						if (redo) alive = w.start(S, w.r.o, w.r.d, w.limit, true);
 						walk_wave(S, w, alive, stk);
 					}
@@ -896,12 +900,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == M
 			}
 		}
 		else {
-			const int nDead = __popcll(__ballot(!alive));
+			const int nDead = __popcll(__builtin_amdgcn_ballot_w64((int)w.cur == -1)); // cur == BVH_DONE <=> !alive here
 			if (!(sup.exhausted() ? nDead == 64 : nDead >= (int)F.refillMin)) { // nothing left to hand out: finish the last rays together
 				// One step for the whole wave: the larger (weighted) group of lanes goes, see walk_wave
-				const bool wantNode = alive && w.at_node();
-				const bool wantLeaf = alive && !wantNode;
-				const int nNode = __popcll(__ballot(wantNode)), nLeaf = __popcll(__ballot(wantLeaf));
+				const bool wantNode = (int)w.cur >= 0, wantLeaf = (int)w.cur < -1;
+				const int nNode = __popcll(__builtin_amdgcn_ballot_w64(wantNode)), nLeaf = __popcll(__builtin_amdgcn_ballot_w64(wantLeaf));
 				if (nNode * MIRT_NODE_WEIGHT >= nLeaf * MIRT_LEAF_WEIGHT) {
 					if (wantNode) w.node_step(S, stk);
 				}
@@ -923,7 +926,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == M
 		bool newHit = false;
 		if (parked) newHit = item_result<PRIMARY>(S, F, T, out, w.r, w.best, w.limit, tag);
 		parked = false;
-		const unsigned long long hm = __ballot(newHit);
+		const unsigned long long hm = __builtin_amdgcn_ballot_w64(newHit);
 		if (hm) {
 			if (newHit) myList[nbuf + (uint32_t)__popcll(hm & ltMask)] = tag;
 			nbuf += (uint32_t)__popcll(hm);
@@ -931,7 +934,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == M
 		}
 		if (REFILL) {
 			// idle lanes take new items
-			const unsigned long long idle = __ballot(!alive);
+			const unsigned long long idle = __builtin_amdgcn_ballot_w64(!alive);
 			uint32_t base = 0;
 			const uint32_t got = sup.take((uint32_t)__popcll(idle), base);
 			const uint32_t rank = (uint32_t)__popcll(idle & ltMask);
@@ -943,7 +946,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == M
 					parked = !alive; // missed the whole scene: result is "no hit"
 				}
 			}
-			if (got == 0 && __ballot(alive || parked) == 0ull) break;
+			if (got == 0 && __builtin_amdgcn_ballot_w64(alive || parked) == 0ull) break;
 		}
 	}
 	if (nbuf) flush_list(myList, nbuf, nextList, F.counters + CTR_NHITS(depth));
