@@ -367,7 +367,11 @@ void launch_frame(mirt_scene* s, FrameCtx* c, const DFrame& F, uint8_t* out, hip
 	int launch = 0;
 	c->nLaunches = 0;
 	mark(s, c, st, -1);
+#ifdef MIRT_ALWAYS_REFILL
+	const bool refill = MODE != MODE_REFWALK;
+#else
 	const bool refill = MODE != MODE_REFWALK && F.refillMin < 64u;
+#endif
 	if (refill) hipLaunchKernelGGL((k_trace<MODE, OVF, true, true>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, out, 0, launch++, 0);
 	else hipLaunchKernelGGL((k_trace<MODE, OVF, true, false>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, out, 0, launch++, 0);
 	mark(s, c, st, MIRT_K_PRIMARY);

@@ -720,8 +720,8 @@ struct Supply {
 // Walks every lane's ray to its end.  One step per iteration for the whole wave: either every lane at an interior node
 // takes a node step, or every lane at a leaf tests one primitive.  (Letting each lane run to its next leaf and through
 // it keeps a wave waiting for its longest descent: measured lane utilisation 0.33 on bounce rays against 0.52 this way.)
-template <int MODE, bool OVF, class STK>
-__device__ __forceinline__ void walk_wave(const DScene& S, Walker<MODE, OVF>& w, bool& alive, STK& stk) {
+template <bool EARLY, int MODE, bool OVF, class STK>
+__device__ __forceinline__ void walk_wave(const DScene& S, Walker<MODE, OVF>& w, STK& stk, uint32_t stopIdle = 65u) {
 	// (Tried and dropped: letting a lane put the leaf it reaches into a small queue of its own and go on with its stack,
 	// so that primitive steps would find more lanes ready -- primitive steps became more frequent and emptier instead.
 	// Also tried and dropped: setting the last <= 12 walking rays of a batch aside (state and stack to a per-wave slice of
@@ -730,18 +730,17 @@ __device__ __forceinline__ void walk_wave(const DScene& S, Walker<MODE, OVF>& w,
 	// leaving a few stragglers: the wave iterations fell by 7 % only, which the extra registers ate.)
 	// A lane without a walk holds cur == BVH_DONE, so both questions are single signed comparisons of cur (node references
 	// are non-negative, leaf references lie below -1) and the ballots come straight from the compare unit.
-	if (!alive) w.cur = BVH_DONE;
+	// Returns when no lane walks any more or, with EARLY, as soon as at least stopIdle lanes do not (65: never).
 	for (;;) {
 		const int c = (int)w.cur;
 		const bool wantNode = c >= 0, wantLeaf = c < -1;
-		const int nNode = __popcll(__builtin_amdgcn_ballot_w64(wantNode)), nLeaf = __popcll(__builtin_amdgcn_ballot_w64(wantLeaf));
-		if (nNode + nLeaf == 0) break;
+		const uint32_t nNode = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(wantNode)), nLeaf = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(wantLeaf));
+		if (nNode + nLeaf == 0u || (EARLY && 64u - (nNode + nLeaf) >= stopIdle)) break;
 		if (nNode * MIRT_NODE_WEIGHT >= nLeaf * MIRT_LEAF_WEIGHT) {
 			if (wantNode) w.node_step(S, stk);
 		}
 		else if (wantLeaf) w.leaf_step(S, stk);
 	}
-	alive = false;
 }
 
 // ---- the tracing kernel: every ray of one depth in one launch ---------------------------------------------------------------
@@ -863,15 +862,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == M
 	Walker<MODE, OVF> w;
 	uint32_t nShadowTraced = 0;
 	uint32_t tag = 0;
-	bool alive = false;
-	bool parked = false; // the lane holds a finished ray whose result is not stored yet
+	bool hasRay = false; // the lane holds a ray: walking (w.cur != BVH_DONE) or finished with its result not stored yet
 	w.cur = BVH_DONE;    // no walk yet
 	for (;;) {
+		bool parked;     // finished rays whose results are stored in this round
 		if (!REFILL) {
 			uint32_t base = 0;
 			const uint32_t got = sup.take(64u, base);
 			if (got == 0) break;
-			alive = false;
+			w.cur = BVH_DONE;
 			parked = false;
 			if ((uint32_t)lane < got) {
 				f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
@@ -884,48 +883,34 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == M
 						w.limit = lim;
 						trace_whole<MODE_REFWALK, OVF>(S, o, d, lim, w.best, stk);
 					}
-					else alive = w.start(S, o, d, lim); // false: missed the whole scene, the result is "no hit"
+					else w.start(S, o, d, lim); // false: missed the whole scene, the result is "no hit"
 				}
 			}
 			if (MODE != MODE_REFWALK) {
-				walk_wave(S, w, alive, stk);
+				walk_wave<false>(S, w, stk);
 				// deferred check of the final answers; the rare ray that fails it is walked again, strictly
 				if (MODE == MODE_EXACT) {
 					const bool redo = parked && !w.verify(S);
 					if (__builtin_amdgcn_ballot_w64(redo)) {
-						if (redo) alive = w.start(S, w.r.o, w.r.d, w.limit, true);
-						walk_wave(S, w, alive, stk);
+						if (redo) w.start(S, w.r.o, w.r.d, w.limit, true);
+						walk_wave<false>(S, w, stk);
 					}
 				}
 			}
 		}
 		else {
-			const int nDead = __popcll(__builtin_amdgcn_ballot_w64((int)w.cur == -1)); // cur == BVH_DONE <=> !alive here
-			if (!(sup.exhausted() ? nDead == 64 : nDead >= (int)F.refillMin)) { // nothing left to hand out: finish the last rays together
-				// One step for the whole wave: the larger (weighted) group of lanes goes, see walk_wave
-				const bool wantNode = (int)w.cur >= 0, wantLeaf = (int)w.cur < -1;
-				const int nNode = __popcll(__builtin_amdgcn_ballot_w64(wantNode)), nLeaf = __popcll(__builtin_amdgcn_ballot_w64(wantLeaf));
-				if (nNode * MIRT_NODE_WEIGHT >= nLeaf * MIRT_LEAF_WEIGHT) {
-					if (wantNode) w.node_step(S, stk);
-				}
-				else if (wantLeaf) w.leaf_step(S, stk);
-				if (alive && w.cur == BVH_DONE) {
-					alive = false;
-					parked = true;
-				}
-				continue;
-			}
+			// walk until enough lanes are idle to make handing out new rays worth a pass through the code below; when nothing
+			// is left to hand out, until the last rays of the wave have finished
+			walk_wave<true>(S, w, stk, sup.exhausted() ? 65u : F.refillMin);
+			parked = hasRay && w.cur == BVH_DONE;
 			// parked lanes make their answer final; the rare ray that fails the check is walked again, strictly
-			if (MODE == MODE_EXACT && parked && !w.verify(S)) {
-				alive = w.start(S, w.r.o, w.r.d, w.limit, true);
-				parked = !alive;
-			}
+			if (MODE == MODE_EXACT && parked && !w.verify(S)) parked = !w.start(S, w.r.o, w.r.d, w.limit, true);
+			if (parked) hasRay = false;
 		}
 		// finished rays store their results; slots with a new hit go to this wave's LDS list, which is appended to the
 		// next depth's list in large pieces
 		bool newHit = false;
 		if (parked) newHit = item_result<PRIMARY>(S, F, T, out, w.r, w.best, w.limit, tag);
-		parked = false;
 		const unsigned long long hm = __builtin_amdgcn_ballot_w64(newHit);
 		if (hm) {
 			if (newHit) myList[nbuf + (uint32_t)__popcll(hm & ltMask)] = tag;
@@ -934,19 +919,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == M
 		}
 		if (REFILL) {
 			// idle lanes take new items
-			const unsigned long long idle = __builtin_amdgcn_ballot_w64(!alive);
+			const unsigned long long idle = __builtin_amdgcn_ballot_w64(!hasRay);
 			uint32_t base = 0;
 			const uint32_t got = sup.take((uint32_t)__popcll(idle), base);
 			const uint32_t rank = (uint32_t)__popcll(idle & ltMask);
-			if (!alive && rank < got) {
+			if (!hasRay && rank < got) {
 				f3 o = F3(0, 0, 0), d = F3(0, 0, 1);
 				float lim;
 				if (item_ray<PRIMARY>(S, F, T, base + rank, o, d, lim, tag, nShadowTraced)) {
-					alive = w.start(S, o, d, lim);
-					parked = !alive; // missed the whole scene: result is "no hit"
+					hasRay = true;
+					w.start(S, o, d, lim); // false (missed the whole scene): cur == BVH_DONE, the next round stores "no hit"
 				}
 			}
-			if (got == 0 && __builtin_amdgcn_ballot_w64(alive || parked) == 0ull) break;
+			if (got == 0 && __builtin_amdgcn_ballot_w64(hasRay) == 0ull) break;
 		}
 	}
 	if (nbuf) flush_list(myList, nbuf, nextList, F.counters + CTR_NHITS(depth));
