@@ -325,7 +325,7 @@ TileGeom tile_geom(const mirt_render_params* p, uint32_t tileW, uint32_t tileH) 
 
 bool packed_layout(const mirt_render_params* p) { return !(p->tile_stride == 1 && p->tile_w == 0 && p->tile_h == 0); }
 
-#define MIRT_MAX_STREAMS 8
+#define MIRT_MAX_STREAMS 16
 FrameCtx* ctx_for(mirt_scene* s, hipStream_t st, bool create) {
 	for (FrameCtx* c : s->ctxs) if (c->stream == st) return c;
 	if (!create) return nullptr;
