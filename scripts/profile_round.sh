@@ -3,6 +3,8 @@
 # Usage: scripts/profile_round.sh <tag>   -> files under gpurun_out/<tag>/ (copy the summaries into profiles/)
 set -o pipefail
 export TMPDIR=/tmp
+# bench.py asks for 16 HIP hardware queues itself, but under rocprofv3 HIP is initialised before Python runs: say it here
+export GPU_MAX_HW_QUEUES=16
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
 T=gpurun_out/$1
