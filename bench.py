@@ -164,7 +164,9 @@ def main():
     stream = streams[(frame_no[0] - 1) % depth].cuda_stream
     local = locals_[(frame_no[0] - 1) % depth]
     st = scene.stats(stream)
-    rays_local = np.array([st["primary_rays"], st["shadow_rays"], st["reflection_rays"]], dtype=np.int64)
+    # counted as the reference spawns them; the last two entries: shadow and reflection rays the device really walked
+    # (a shadow query whose light term is multiplied by an exact zero is answered without a walk)
+    rays_local = np.array([st["primary_rays"], st["shadow_rays"], st["reflection_rays"], st["shadow_rays_traced"], st["reflection_rays_traced"]], dtype=np.int64)
 
     def collect(frames):
         acc = {}
@@ -192,7 +194,7 @@ def main():
         rays = rays_local
 
     if rank == 0:
-        total_rays = int(rays.sum())
+        total_rays = int(rays[:3].sum())
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rays * args.steps / elapsed / 1e6
         out = {
@@ -207,6 +209,7 @@ def main():
                 "scene_source": "scene text parsed and Partition tree built by the library's host loader in %.2f s (%d nodes, %d leaf entries)" % (flat.parse_seconds + flat.build_seconds, flat.nodes.shape[0], flat.leaf_prims.shape[0]),
             },
             "rays_per_frame": {"primary": int(rays[0]), "shadow": int(rays[1]), "reflection": int(rays[2])},
+            "rays_walked_per_frame": {"primary": int(rays[0]), "shadow": int(rays[3]), "reflection": int(rays[4])},
             "kernels": kern,
             "kernels_alone": kern_alone,
         }

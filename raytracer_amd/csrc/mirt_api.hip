@@ -864,6 +864,20 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	ds.nLights = d->n_lights;
 	ds.maxDepth = d->max_depth;
 	for (int k = 0; k < 3; ++k) ds.atten[k] = d->attenuation[k];
+	// Shadow queries whose light term is multiplied by an exact zero are not traced (item_ray).  That needs products
+	// that cannot turn into inf or NaN on the way -- every material and light colour finite and modest -- and
+	// pow(0, shininess) = 0, i.e. shininess > 0, everywhere.  MIRT_SHADOW_CULL=0 switches it off (measurements).
+	{
+		bool ok = true;
+		for (uint32_t i = 0; i < d->n_materials && ok; ++i) {
+			const mirt_material& m = d->materials[i];
+			for (int k = 0; k < 3; ++k) ok = ok && fabsf(m.diffuse[k]) <= 1e15f && fabsf(m.specular[k]) <= 1e15f;
+			ok = ok && m.shininess > 0.0f && std::isfinite(m.shininess);
+		}
+		for (uint32_t i = 0; i < d->n_lights && ok; ++i) for (int k = 0; k < 3; ++k) ok = ok && fabsf(d->lights[i].color[k]) <= 1e15f;
+		if (const char* env = getenv("MIRT_SHADOW_CULL")) ok = ok && atoi(env) != 0;
+		ds.shadowCull = ok ? 1u : 0u;
+	}
 	s->nLights = d->n_lights;
 	s->maxDepth = d->max_depth;
 

@@ -84,6 +84,7 @@ struct DScene {
 	uint32_t nLights;
 	int32_t maxDepth;
 	float atten[3];
+	uint32_t shadowCull; // 1: shadow queries whose light term is provably multiplied by zero may be skipped (host-checked premises)
 	DCamera cam;
 };
 

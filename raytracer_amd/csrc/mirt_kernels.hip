@@ -792,8 +792,28 @@ __device__ __forceinline__ bool item_ray(const DScene& S, const DFrame& F, const
 		const float4 ll = S.lights[li * 2];
 		const f3 L = ll.w > 0.0f ? F3(ll) - o : F3(ll);           // main.cpp:213-219
 		d = normalize3(L);                                        // :222
-		lim = F.debug == D_SHADOW_MAP ? -2.0f : length3(L);       // :224
+		const float dl = length3(L);
+		lim = F.debug == D_SHADOW_MAP ? -2.0f : dl;               // :224
 		tag = slot * S.nLights + li;
+		// The answer of this query decides whether lc * atten * (diffuse * kd + specular * ks) is added (main.cpp:224-247).
+		// If kd and ks -- evaluated here with k_shade's own operations on the same values -- are both exact zeros and no
+		// factor can be inf or NaN (S.shadowCull, finite attenuation), the sum is the same either way: the query is
+		// answered "not occluded" without a walk.  Such rays stay in the reference's count (mirt_stats.shadow_rays) and
+		// are left out of shadow_rays_traced.
+		if (S.shadowCull && F.debug == D_NONE) {
+			const f3 N = F3(F.hitN[T.rd + slot]);
+			const bool kd0 = !(F.features & F_DIFFUSE) || !(dot3(normalize3(N), normalize3(L)) > 0.0f);  // fmaxf(x, 0) == 0
+			bool ks0 = !(F.features & F_SPECULAR);
+			if (!ks0) {
+				const f3 H = normalize3(d + normalize3(po - o));      // main.cpp:226-227
+				ks0 = !(dot3(H, N) > 0.0f);                           // pow(0, shininess > 0) == 0
+			}
+			const float atten = ll.w > 0.0f ? 1.0f / (S.atten[0] + S.atten[1] * dl + S.atten[2] * (dl * dl)) : 1.0f; // :266-268
+			if (kd0 && ks0 && fabsf(atten) <= 1e15f) {
+				F.shRes[tag] = make_uint2(REF_NONE, __float_as_uint(__builtin_inff()));
+				return false;
+			}
+		}
 		++nShadowTraced;
 	}
 	else {

@@ -78,6 +78,28 @@ def test_lane_refilling_variant_exact(name, refill_min, flat_scenes, goldens, mo
             assert np.array_equal(img, g["bgr_debug%d" % debug])
 
 
+@pytest.mark.parametrize("name", ["scene5", "scene6", "scene7"])
+def test_shadow_queries_with_zero_light_terms_are_not_walked(name, flat_scenes, goldens, monkeypatch):
+    """A shadow query whose light term is multiplied by exact zeros (kd == 0 and ks == 0) is answered without a walk: the
+    image and the reference's ray counts stay the same, only shadow_rays_traced drops; MIRT_SHADOW_CULL=0 walks them all."""
+    from raytracer_amd.device import DeviceScene
+    g = goldens(name)
+    w, h = int(g["width"]), int(g["height"])
+    traced = {}
+    for cull in ("1", "0"):
+        monkeypatch.setenv("MIRT_SHADOW_CULL", cull)
+        with DeviceScene(flat_scenes(name), 0) as s:
+            for features in (15, 7, 11):
+                img, st = s.render(w, h, features=features)
+                assert np.array_equal(img, g["bgr_f%d" % features]), (cull, features)
+                assert [st["primary_rays"], st["shadow_rays"], st["reflection_rays"]] == g["rays_f%d" % features].tolist()
+                traced[cull, features] = st["shadow_rays_traced"]
+                if cull == "0" and features & 4:  # with SHADOWS off no query is walked at all
+                    assert st["shadow_rays_traced"] == st["shadow_rays"]
+    assert all(traced["1", f] <= traced["0", f] for f in (15, 7, 11))
+    assert traced["1", 15] < traced["0", 15]
+
+
 @pytest.mark.parametrize("name", ["scene1", "scene5", "scene6", "scene7"])
 @pytest.mark.parametrize("debug", range(_capi.DEBUG_NONE))
 def test_render_exact_debug_views(name, debug, dev_scenes, goldens):
