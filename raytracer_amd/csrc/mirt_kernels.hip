@@ -159,8 +159,10 @@ __device__ __forceinline__ float tri_hit(const RayCtx& r, const float4* __restri
 	// The plane in ONE 16-byte load: left to itself the compiler fetches dot(v1,N) only after the first test, one more
 	// trip to memory on the path of nearly every test (+3 % when avoided).  Fetching the whole record up front, for one
 	// trip instead of two, loses 2 %: a quarter of the tests end at the plane.
+	// (Inline asm rather than a volatile access: that would become a FLAT load with system-scope cache policy.)
 	typedef float v4f __attribute__((ext_vector_type(4)));
-	const v4f w0 = *(const volatile v4f*)T;
+	v4f w0;
+	asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(w0) : "v"(T) : "memory");
 	const float4 q0 = make_float4(w0.x, w0.y, w0.z, w0.w);
 	const f3 N = F3(q0);
 	const float dn = dot3(r.d, N);
