@@ -687,6 +687,9 @@ __device__ __forceinline__ void flush_list(const uint32_t* lds, uint32_t n, uint
 // cursor per launch.  The block size adapts to the launch: 256 items when there is plenty of work (one atomic per 256
 // items keeps the cursor word far below the ~88 atomics/us one address sustains), down to 64 when there is little, so
 // that a small launch spreads over many waves instead of queueing on a few.
+// (Measured alternative: the items cut into 8 contiguous ranges, one per XCD -- workgroup i runs on XCD i % 8 -- each with
+// a cursor of its own and stealing from the next range when empty, so that an XCD's L2 serves one part of the image: the
+// uneven cost of the parts loses far more than the L2 gains, Stanford dragon -35 %, 10 M triangles -11 %.)
 struct Supply {
 	uint32_t* cursor;
 	uint32_t n, cb, ce, stride0, blk;
