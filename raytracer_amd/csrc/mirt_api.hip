@@ -14,6 +14,7 @@
 #include <chrono>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #pragma clang fp contract(off)
@@ -338,6 +339,22 @@ FrameCtx* ctx_for(mirt_scene* s, hipStream_t st, bool create) {
 	return c;
 }
 
+// fn(i) for every i < n on up to 16 threads; the iterations must not depend on each other
+template <class F>
+void parallel_for(uint32_t n, F fn) {
+	unsigned nt = std::thread::hardware_concurrency();
+	nt = nt > 16 ? 16 : (nt < 1 ? 1 : nt);
+	if (n < 65536u || nt == 1) { for (uint32_t i = 0; i < n; ++i) fn(i); return; }
+	std::vector<std::thread> th;
+	const uint32_t per = (n + nt - 1) / nt;
+	for (unsigned t = 0; t < nt; ++t) {
+		const uint32_t a = t * per, b = a + per < n ? a + per : n;
+		if (a >= b) break;
+		th.emplace_back([=]() { for (uint32_t i = a; i < b; ++i) fn(i); });
+	}
+	for (auto& x : th) x.join();
+}
+
 // a tree whose boxes are not nested is walked as it is, whatever mode was asked for
 int effective_mode(const mirt_scene* s, uint32_t mode) { return s->nested ? (int)mode : MODE_REFWALK; }
 
@@ -543,28 +560,35 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	for (uint32_t i = 0; i < d->n_spheres; ++i) primSlot[d->sphere_prim[i]] = -1 - (int64_t)i;
 
 	// ---- membership lists: per primitive, the reference leaves holding it, in visiting order ------------------------
+	// (Nodes are handled in parallel: counts and slots by atomic increments, then every primitive's few entries are put
+	// into visiting order by their rank, so the lists do not depend on the thread count.)
 	std::vector<uint32_t> mCnt(d->n_prims, 0), mOfs(d->n_prims + 1, 0);
-	for (uint32_t i = 0; i < d->n_nodes; ++i) {
+	parallel_for(d->n_nodes, [&](uint32_t i) {
 		const mirt_node& n = d->nodes[i];
-		if (!(n.b & MIRT_LEAF_FLAG)) continue;
+		if (!(n.b & MIRT_LEAF_FLAG)) return;
 		const uint32_t cnt = n.b & ~MIRT_LEAF_FLAG;
-		for (uint32_t k = 0; k < cnt; ++k) mCnt[d->leaf_prims[n.a + k]]++;
-	}
+		for (uint32_t k = 0; k < cnt; ++k) __atomic_fetch_add(&mCnt[d->leaf_prims[n.a + k]], 1u, __ATOMIC_RELAXED);
+	});
 	for (uint32_t p = 0; p < d->n_prims; ++p) mOfs[p + 1] = mOfs[p] + mCnt[p];
 	std::vector<float> memb((size_t)mOfs[d->n_prims] * 8, 0.0f);
 	{
 		std::vector<uint32_t> fill(mOfs.begin(), mOfs.end() - 1);
-		for (uint32_t i = 0; i < d->n_nodes; ++i) {
+		parallel_for(d->n_nodes, [&](uint32_t i) {
 			const mirt_node& n = d->nodes[i];
-			if (!(n.b & MIRT_LEAF_FLAG)) continue;
+			if (!(n.b & MIRT_LEAF_FLAG)) return;
 			const uint32_t cnt = n.b & ~MIRT_LEAF_FLAG;
 			for (uint32_t k = 0; k < cnt; ++k) {
 				const uint32_t pos = n.a + k; // rank in the reference's visiting order
-				float* m = memb.data() + (size_t)fill[d->leaf_prims[pos]]++ * 8;
+				float* m = memb.data() + (size_t)__atomic_fetch_add(&fill[d->leaf_prims[pos]], 1u, __ATOMIC_RELAXED) * 8;
 				m[0] = n.bmin[0]; m[1] = n.bmin[1]; m[2] = n.bmin[2]; memcpy(m + 3, &pos, 4);
 				m[4] = n.bmax[0]; m[5] = n.bmax[1]; m[6] = n.bmax[2]; m[7] = 0.0f;
 			}
-		}
+		});
+		parallel_for(d->n_prims, [&](uint32_t p) {
+			struct Entry { float f[8]; };
+			Entry* e = (Entry*)(memb.data() + (size_t)mOfs[p] * 8);
+			std::sort(e, e + mCnt[p], [](const Entry& a, const Entry& b) { uint32_t x, y; memcpy(&x, a.f + 3, 4); memcpy(&y, b.f + 3, 4); return x < y; });
+		});
 	}
 	// the hierarchy-plus-membership formulation needs child boxes nested in parent boxes (see mirt_bvh.h)
 	bool nested = true;
@@ -794,7 +818,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	std::vector<float> tris((size_t)d->n_triangles * TRI_F4 * 4, 0.0f);
 	std::vector<float> triX((size_t)d->n_triangles * 8, 0.0f);
 	std::vector<uint32_t> triInfo((size_t)d->n_triangles * 4, 0);
-	for (uint32_t ni = 0; ni < d->n_triangles; ++ni) {
+	parallel_for(d->n_triangles, [&](uint32_t ni) {
 		const uint32_t i = triOld[ni];
 		const float* v = d->tri_verts + (size_t)i * 9;
 		const h3 v1 = H3(v[0], v[1], v[2]), v2 = H3(v[3], v[4], v[5]), v3 = H3(v[6], v[7], v[8]);
@@ -811,7 +835,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		const uint32_t prim = d->tri_prim[i];
 		uint32_t* inf = triInfo.data() + (size_t)ni * 4;
 		inf[0] = prim; inf[1] = d->prim_material[prim]; inf[2] = mOfs[prim]; inf[3] = mCnt[prim];
-	}
+	});
 	// spheres: { c, powf(r,2) } M[4] Minv[4]
 	std::vector<float> sph((size_t)d->n_spheres * SPHERE_F4 * 4, 0.0f);
 	std::vector<uint32_t> sphInfo((size_t)d->n_spheres * 4, 0);
