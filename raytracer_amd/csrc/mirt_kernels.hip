@@ -437,13 +437,14 @@ struct Walker {
 	// at every candidate runs at ~6 % lane utilisation, so the walk normally defers it: it keeps the nearest candidate
 	// unverified and the caller verifies the final answer once (verify()), many lanes at a time.  Only if that check
 	// fails, or two different primitives tie in distance (the rank decides, Partition.h:33 / Partition.cpp:47), is the
-	// ray walked again in strict mode, where every candidate is checked on the spot.
-	bool strict, needStrict;
+	// ray walked again in strict mode, where every candidate is checked on the spot.  The two kinds of walk are separate
+	// instantiations (STRICT) of the stepping functions, so the common one carries neither the membership code nor the
+	// visiting rank through its loop.
+	bool needStrict;
 
-	__device__ __forceinline__ bool start(const DScene& S, f3 o, f3 d, float lim, bool strictMode = false) {
+	__device__ __forceinline__ bool start(const DScene& S, f3 o, f3 d, float lim) {
 		r = make_ray(o, d);
 		limit = lim;
-		strict = strictMode || MODE != MODE_EXACT;
 		needStrict = false;
 		best.dist = __builtin_inff();
 		best.ref = REF_NONE;
@@ -520,6 +521,7 @@ struct Walker {
 
 	// Tests the first record of leaf reference `lf` against the ray and updates the best hit.  Returns true if the walk
 	// is over (a shadow query found its occluder, or a distance tie asks for the strict walk).
+	template <bool STRICT>
 	__device__ __forceinline__ bool test_first(const DScene& S, uint32_t lf) {
 		STAT_WAVE(S, 2); // primitive tests (wave iterations)
 		STAT_LANE(S, 3); // primitive tests (lanes)
@@ -541,7 +543,7 @@ struct Walker {
 		if (!cand) return false;
 		uint32_t pos = 0;
 		if (MODE == MODE_EXACT) {
-			if (!strict) {
+			if (!STRICT) {
 				if (tie) { needStrict = true; return true; }
 			}
 			else {
@@ -555,14 +557,15 @@ struct Walker {
 		if (any) {
 			best.dist = dist;
 			best.ref = ref;
-			best.pos = pos;
+			if (STRICT) best.pos = pos;
 			return true;
 		}
 		// Partition.h:33 (first in a leaf wins), Partition.cpp:47 (left subtree wins) == lower visiting rank wins
-		if (dist < best.dist || pos < best.pos) {
+		// (without ranks, i.e. not STRICT, a tie has already ended the walk above, or -- MODE_FAST -- the first found stays)
+		if (dist < best.dist || (STRICT && MODE == MODE_EXACT && pos < best.pos)) {
 			best.dist = dist;
 			best.ref = ref;
-			best.pos = pos;
+			if (STRICT) best.pos = pos;
 			tcull = dist * r.invLen * 1.0001f + 1e-5f;
 		}
 		return false;
@@ -574,9 +577,9 @@ struct Walker {
 
 	// One primitive of the current leaf (1..8 consecutive records of one kind).  Call only while cur is a leaf.
 	// Afterwards cur is the rest of the leaf, or the next stack entry, or BVH_DONE.  Returns true while the same leaf goes on.
-	template <class STK>
+	template <bool STRICT, class STK>
 	__device__ __forceinline__ bool leaf_step(const DScene& S, STK& stk) {
-		if (test_first(S, cur)) { cur = BVH_DONE; sp = 0; return false; }
+		if (test_first<STRICT>(S, cur)) { cur = BVH_DONE; sp = 0; return false; }
 		const uint32_t rest = leaf_rest(cur);
 		if (rest) { cur = rest; return true; }
 		cur = sp > 0 ? stk.pop(--sp) : BVH_DONE;
@@ -584,19 +587,19 @@ struct Walker {
 	}
 
 	// One round: descend to the next leaf, test its primitives, pop.  Returns false when the walk is over.
-	template <class STK>
+	template <bool STRICT, class STK>
 	__device__ __forceinline__ bool advance(const DScene& S, STK& stk) {
 		STAT_WAVE(S, 6); // advance rounds (wave)
 		STAT_LANE(S, 7); // advance rounds (lanes)
 		while (at_node()) node_step(S, stk);
 		if (cur == BVH_DONE) return false;
-		while (leaf_step(S, stk)) {}
+		while (leaf_step<STRICT>(S, stk)) {}
 		return cur != BVH_DONE;
 	}
 
-	// After a deferred walk has ended: is its answer final?  false = walk the ray again with start(..., strict = true).
+	// After a deferred (not STRICT) walk has ended: is its answer final?  false = walk the ray again, STRICT.
 	__device__ __forceinline__ bool verify(const DScene& S) const {
-		if (strict) return true;
+		if (MODE != MODE_EXACT) return true;
 		if (needStrict) return false;
 		if (best.ref == REF_NONE) return true;
 		STAT_WAVE(S, 4);
@@ -617,10 +620,10 @@ __device__ __forceinline__ void trace_whole(const DScene& S, f3 o, f3 d, float l
 	}
 	Walker<MODE == MODE_REFWALK ? MODE_EXACT : MODE, OVF> w;
 	bool alive = w.start(S, o, d, limit);
-	while (alive) alive = w.advance(S, stk);
+	while (alive) alive = w.template advance<false>(S, stk);
 	if (!w.verify(S)) {
-		alive = w.start(S, o, d, limit, true);
-		while (alive) alive = w.advance(S, stk);
+		alive = w.start(S, o, d, limit);
+		while (alive) alive = w.template advance<true>(S, stk);
 	}
 	best = w.best;
 }
@@ -730,7 +733,7 @@ struct Supply {
 // Walks every lane's ray to its end.  One step per iteration for the whole wave: either every lane at an interior node
 // takes a node step, or every lane at a leaf tests one primitive.  (Letting each lane run to its next leaf and through
 // it keeps a wave waiting for its longest descent: measured lane utilisation 0.33 on bounce rays against 0.52 this way.)
-template <bool EARLY, int MODE, bool OVF, class STK>
+template <bool EARLY, bool STRICT, int MODE, bool OVF, class STK>
 __device__ __forceinline__ void walk_wave(const DScene& S, Walker<MODE, OVF>& w, STK& stk, uint32_t stopIdle = 65u) {
 	// (Tried and dropped: letting a lane put the leaf it reaches into a small queue of its own and go on with its stack,
 	// so that primitive steps would find more lanes ready -- primitive steps became more frequent and emptier instead.
@@ -749,7 +752,7 @@ __device__ __forceinline__ void walk_wave(const DScene& S, Walker<MODE, OVF>& w,
 		if (nNode * MIRT_NODE_WEIGHT >= nLeaf * MIRT_LEAF_WEIGHT) {
 			if (wantNode) w.node_step(S, stk);
 		}
-		else if (wantLeaf) w.leaf_step(S, stk);
+		else if (wantLeaf) w.template leaf_step<STRICT>(S, stk);
 	}
 }
 
@@ -917,13 +920,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == M
 				}
 			}
 			if (MODE != MODE_REFWALK) {
-				walk_wave<false>(S, w, stk);
+				walk_wave<false, false>(S, w, stk);
 				// deferred check of the final answers; the rare ray that fails it is walked again, strictly
 				if (MODE == MODE_EXACT) {
 					const bool redo = parked && !w.verify(S);
 					if (__builtin_amdgcn_ballot_w64(redo)) {
-						if (redo) w.start(S, w.r.o, w.r.d, w.limit, true);
-						walk_wave<false>(S, w, stk);
+						if (redo) w.start(S, w.r.o, w.r.d, w.limit);
+						walk_wave<false, true>(S, w, stk);
 					}
 				}
 			}
@@ -931,10 +934,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == M
 		else {
 			// walk until enough lanes are idle to make handing out new rays worth a pass through the code below; when nothing
 			// is left to hand out, until the last rays of the wave have finished
-			walk_wave<true>(S, w, stk, sup.exhausted() ? 65u : F.refillMin);
+			walk_wave<true, false>(S, w, stk, sup.exhausted() ? 65u : F.refillMin);
 			parked = hasRay && w.cur == BVH_DONE;
-			// parked lanes make their answer final; the rare ray that fails the check is walked again, strictly
-			if (MODE == MODE_EXACT && parked && !w.verify(S)) parked = !w.start(S, w.r.o, w.r.d, w.limit, true);
+			// parked lanes make their answer final; the rare ray that fails the check is walked again, strictly, to its end
+			// while the lanes that are still on their way wait
+			if (MODE == MODE_EXACT) {
+				const bool redo = parked && !w.verify(S);
+				if (__builtin_amdgcn_ballot_w64(redo)) {
+					const uint32_t waiting = w.cur;
+					if (redo) w.start(S, w.r.o, w.r.d, w.limit);
+					else w.cur = BVH_DONE;
+					walk_wave<false, true>(S, w, stk);
+					if (!redo) w.cur = waiting;
+				}
+			}
 			if (parked) hasRay = false;
 		}
 		// finished rays store their results; slots with a new hit go to this wave's LDS list, which is appended to the
