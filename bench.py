@@ -72,6 +72,23 @@ def cpu_baseline_and_visits(flat, scene_text, width, height, row_step, use_refer
         assert [rs["primary"], rs["shadow"], rs["reflection"]] == rays, "reference and restatement disagree on ray counts"
         base = {"value": n / rs["seconds"] / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference",
                 "sample": sample + "; reference classes compiled unmodified (g++ -O2), pixel loop only, shading driver of main.cpp restated"}
+        # the reference has no threads; what all host cores could do: P processes, each with the reference's own scene
+        # and its own rows (every 4th row of the image, dealt round-robin), rays summed over the slowest worker's loop time
+        try:
+            import subprocess
+            P = min(16, os.cpu_count() or 1)
+            with tempfile.NamedTemporaryFile("wb", suffix=".test", delete=False) as f:
+                f.write(scene_text)
+            try:
+                procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_rows", f.name, str(width), str(height), str(4 * p), str(4 * P)],
+                                          cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for p in range(P)]
+                outs = [json.loads(pr.communicate(timeout=300)[0]) for pr in procs]
+            finally:
+                os.unlink(f.name)
+            base["all_cores"] = {"value": sum(o["rays"] for o in outs) / max(o["seconds"] for o in outs) / 1e6, "unit": "Mrays/s", "cores": P,
+                                 "sample": "every 4th row, %d processes" % P}
+        except Exception as exc:  # the one-core figure above is the baseline; this one is an extra
+            base["all_cores"] = {"error": str(exc)[:200]}
     return base, st["visits"], rays
 
 
