@@ -750,6 +750,9 @@ __device__ __forceinline__ void walk_wave(const DScene& S, Walker<MODE, OVF>& w,
 		const uint32_t nNode = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(wantNode)), nLeaf = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(wantLeaf));
 		if (nNode + nLeaf == 0u || (EARLY && 64u - (nNode + nLeaf) >= stopIdle)) break;
 		if (nNode * MIRT_NODE_WEIGHT >= nLeaf * MIRT_LEAF_WEIGHT) {
+#if MIRT_STATS
+			if (wantNode) STAT_WAVE(S, 8 + ((nNode + nLeaf - 1u) >> 3)); // histogram of node steps by walking lanes (at nodes or leaves), 8 per bucket
+#endif
 			if (wantNode) w.node_step(S, stk);
 		}
 		else if (wantLeaf) w.template leaf_step<STRICT>(S, stk);

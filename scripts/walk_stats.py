@@ -14,7 +14,7 @@ if name in ("grid", "spheres", "cornell", "dragon"):  # generated workloads
     flat = FlatScene.from_text(gen[name](w, h))
 else:
     flat = FlatScene.load(os.path.join(ROOT, "tests", "golden", name + ".flat.npz"))
-names = ["node_wave", "node_lane", "prim_wave", "prim_lane", "memb_wave", "memb_lane", "round_wave", "round_lane"]
+names = ["node_wave", "node_lane", "prim_wave", "prim_lane", "memb_wave", "memb_lane", "round_wave", "round_lane"]  # 100..107; 108..115: histogram
 def read(s):
     out = {}
     for i, n in enumerate(names):
@@ -33,5 +33,12 @@ with DeviceScene(flat, 0) as s:
         fb = C.c_uint64()
         if s.lib.mirt_scene_query(s.h, 116, C.byref(fb)) == 0:
             print("  triangle filter fallbacks: %d (%.2e of primitive tests)" % (fb.value, fb.value / max(1, c["prim_lane"])))
+        hist = []
+        for b in range(8):
+            v = C.c_uint64()
+            s.lib.mirt_scene_query(s.h, 108 + b, C.byref(v))
+            hist.append(v.value)
+        if sum(hist):
+            print("  node steps by walking lanes of the wave (1-8, 9-16, ..., 57-64): " + " ".join("%.3f" % (h / sum(hist)) for h in hist))
         for k in ("node", "prim", "memb", "round"):
             print("  %-6s lane utilisation %.2f  (wave iterations %d)" % (k, c[k + "_lane"] / max(1, 64 * c[k + "_wave"]), c[k + "_wave"]))
