@@ -737,10 +737,14 @@ template <bool EARLY, bool STRICT, int MODE, bool OVF, class STK>
 __device__ __forceinline__ void walk_wave(const DScene& S, Walker<MODE, OVF>& w, STK& stk, uint32_t stopIdle = 65u) {
 	// (Tried and dropped: letting a lane put the leaf it reaches into a small queue of its own and go on with its stack,
 	// so that primitive steps would find more lanes ready -- primitive steps became more frequent and emptier instead.
-	// Also tried and dropped: setting the last <= 12 walking rays of a batch aside (state and stack to a per-wave slice of
-	// global memory) and resuming them 64 at a time at the end of the launch.  On the Stanford dragon 40 % of all lane
-	// slots belong to rays that are already finished, but the number of walking lanes decays gradually rather than
-	// leaving a few stragglers: the wave iterations fell by 7 % only, which the extra registers ate.)
+	// Also tried and dropped, twice: setting the last few walking rays of a batch aside and walking them on later, 64 to a
+	// wave again.  On the Stanford dragon 30 % of the node steps are taken by waves with at most 16 walking lanes
+	// (scripts/walk_stats.py prints the histogram), and with the last <= 16 rays of every batch written to a pool (96 B:
+	// ray, bound, best candidate, position, 11 stack entries) and a second launch per depth that walks the pool, the wave
+	// iterations fall by 16 % and node-step lane utilisation rises from 0.57 to 0.68 -- but a quarter of all rays then
+	// passes through the pool (0.6 GB per 4K frame on a memory path that is already 80 % busy, plus their set-up twice)
+	// and the frame rate FALLS by 9 % (<= 8 rays set aside), 13 % (16), 19 % (32).  An earlier form with per-wave slices of
+	// global memory and <= 12 rays lost the same way.)
 	// A lane without a walk holds cur == BVH_DONE, so both questions are single signed comparisons of cur (node references
 	// are non-negative, leaf references lie below -1) and the ballots come straight from the compare unit.
 	// Returns when no lane walks any more or, with EARLY, as soon as at least stopIdle lanes do not (65: never).
