@@ -82,3 +82,21 @@ def test_every_primitive_of_small_scenes(tmp_path):
             hit = ~np.isinf(want)
             assert np.array_equal(bits(wn[hit]), bits(gn[hit])), (name, p)
         ref.close()
+
+
+def test_cpu_rows_workers_cover_the_sample_once(tmp_path):
+    """bench.py's all-cores CPU figure: P worker processes, each with rows r0, r0 + step, ...; together they trace
+    exactly the rays of the sampled rows."""
+    import json
+    import subprocess
+    import sys
+    path = _scene_file("scene6", 64, 48, tmp_path)
+    ref = RefOracle(path)
+    _, whole = ref.render(64, 48, row_step=4)
+    ref.close()
+    P = 3
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = [json.loads(subprocess.run([sys.executable, "-m", "oracle.cpu_rows", path, "64", "48", str(4 * p), str(4 * P)], cwd=root,
+                                      check=True, capture_output=True, timeout=120).stdout) for p in range(P)]
+    assert sum(o["rays"] for o in outs) == whole["primary"] + whole["shadow"] + whole["reflection"]
+    assert all(o["seconds"] > 0 for o in outs)
