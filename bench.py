@@ -37,6 +37,8 @@ if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 16:
 
 HBM_PEAK_GBS = 8000.0
 NODE_BYTES, TRI_BYTES, SPHERE_BYTES, RAY_STATE_BYTES = 32, 40, 116, 32
+FP32_PEAK_TFLOPS = 157.3
+NODE_FLOPS, TRI_FLOPS, SPHERE_FLOPS = 24, 60, 120
 
 # name -> (scene text generator in raytracer_amd.workloads, N=1 size, description).  "dragon" is the configuration the
 # metric is quoted on; the others are the remaining BASELINE configurations, selectable for extra measurements.
@@ -243,6 +245,9 @@ def main():
                 n = max(int(srays[k]), 1)
                 per_ray.append((float(vis[k][0]) * NODE_BYTES + float(vis[k][2]) * (TRI_BYTES if flat.tri_verts.shape[0] >= flat.spheres.shape[0] else SPHERE_BYTES)) / n + RAY_STATE_BYTES)
             frame_bytes = float(rays[0]) * per_ray[0] + float(rays[1]) * per_ray[1] + float(rays[2]) * per_ray[2] + width * height * 3
+            # the same visit counts priced in flops (box test 24, triangle test 60, sphere test 120): the secondary roofline
+            prim_flops = (TRI_FLOPS if flat.tri_verts.shape[0] >= flat.spheres.shape[0] else SPHERE_FLOPS)
+            frame_flops = sum(float(rays[k]) * (float(vis[k][0]) * NODE_FLOPS + float(vis[k][2]) * prim_flops) / max(int(srays[k]), 1) for k in range(3))
             # dominant kernels: everything that walks the tree (primary + trace + shade); resolve is the remainder
             walk_ms = sum(kern[k]["ms_per_frame"] for k in ("primary", "trace", "shade") if k in kern)
             achieved = frame_bytes / (walk_ms * 1e-3) / 1e9
@@ -259,6 +264,9 @@ def main():
                 "note": "bytes = reference-semantics exhaustive walk (box tests x32 B + triangle tests x40 B + 32 B ray state); the device walk is ordered and culled, so it touches far fewer",
                 # launches of the frames in flight share the GPU, so their event durations add up to more than a frame's
                 # share of the wall clock; the same bytes over ms_per_step and over the launches of a frame run alone:
+                "secondary": {"bound": "fp32 vector", "achieved": frame_flops / (walk_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": frame_flops / (walk_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "algorithmic_flops_per_frame": frame_flops,
+                              "achieved_per_step": frame_flops / (elapsed / args.steps) / 1e12},
                 "achieved_per_step_GBs": frame_bytes / (elapsed / args.steps) / 1e9,
                 "achieved_frame_alone_GBs": frame_bytes / (sum(kern_alone[k]["ms_per_frame"] for k in ("primary", "trace", "shade") if k in kern_alone) * 1e-3) / 1e9,
             }
