@@ -44,6 +44,7 @@ NODE_FLOPS, TRI_FLOPS, SPHERE_FLOPS = 24, 60, 120
 # metric is quoted on; the others are the remaining BASELINE configurations, selectable for extra measurements.
 WORKLOADS = {
     "dragon": ("dragon", (3840, 2160), "final_scenes/scene7 (Stanford Dragon, 100000 triangles, 1 point light) %dx%d maxdepth 5"),
+    "dragon8k": ("dragon", (7680, 4320), "final_scenes/scene7 (Stanford Dragon, 100000 triangles, 1 point light) %dx%d maxdepth 5"),
     "cornell": ("cornell", (640, 480), "final_scenes/scene6 (Cornell box, 34 triangles + 4 spheres, 2 lights) %dx%d maxdepth 5"),
     "spheres": ("spheres", (1920, 1080), "final_scenes/scene5 + 200 ellipsoids (1200 spheres, 2 lights) %dx%d maxdepth 5"),
     "grid": ("dragon_grid", (3840, 2160), "10x10 Stanford dragons (10000000 triangles, 16 point lights) %dx%d maxdepth 8"),
@@ -130,8 +131,10 @@ def main():
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     gen, (w1, h1), describe = WORKLOADS[args.workload]
-    width = args.width or (w1 if world == 1 else 2 * w1)   # N > 1: the 8K frame of the Dragon, cut over the ranks
-    height = args.height or (h1 if world == 1 else 2 * h1)
+    # the same frame for every N (strong scaling of the configuration the metric is quoted on); the 7680x4320 frame of
+    # BASELINE configs[3] is --workload dragon8k, with an N = 1 run of its own
+    width = args.width or w1
+    height = args.height or h1
     trace_mode = _capi.TRACE_FAST if args.trace_mode == "fast" else _capi.TRACE_EXACT
     # scene text -> the library's own parser and Partition build (mirt_host_scene_parse) -> flattened scene
     scene_text = getattr(workloads, gen)(width, height)
@@ -183,6 +186,19 @@ def main():
     stream = streams[(frame_no[0] - 1) % depth].cuda_stream
     local = locals_[(frame_no[0] - 1) % depth]
     st = scene.stats(stream)
+    # Self-check of the timed mode: the last frame of EVERY stream (rendered with the other streams' frames in flight)
+    # must equal a frame rendered alone on a stream of its own, byte for byte; no figure is printed otherwise.
+    check_stream = torch.cuda.Stream()
+    check = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    with torch.cuda.stream(check_stream):
+        scene.render_device(params, check.data_ptr(), nbytes, check_stream.cuda_stream)
+    torch.cuda.synchronize()
+    bad = [k for k in range(depth) if not torch.equal(locals_[k], check)]
+    if bad:
+        raise SystemExit("bench self-check FAILED: frames of streams %s differ from the frame rendered alone" % bad)
+    if not bool(check.any()):
+        raise SystemExit("bench self-check FAILED: the frame is all black")
+    scene.release_stream(check_stream.cuda_stream)
     # counted as the reference spawns them; the last two entries: shadow and reflection rays the device really walked
     # (a shadow query whose light term is multiplied by an exact zero is answered without a walk)
     rays_local = np.array([st["primary_rays"], st["shadow_rays"], st["reflection_rays"], st["shadow_rays_traced"], st["reflection_rays_traced"]], dtype=np.int64)
@@ -229,6 +245,7 @@ def main():
             },
             "rays_per_frame": {"primary": int(rays[0]), "shadow": int(rays[1]), "reflection": int(rays[2])},
             "rays_walked_per_frame": {"primary": int(rays[0]), "shadow": int(rays[3]), "reflection": int(rays[4])},
+            "self_check": "last frame of each of the %d streams byte-equal to a frame rendered alone" % depth,
             "kernels": kern,
             "kernels_alone": kern_alone,
         }

@@ -184,6 +184,10 @@ int mirt_render(mirt_scene* scene, const mirt_render_params* params, uint8_t* bg
  * a queue do not overlap: give the process at least as many queues as frames in flight. */
 int mirt_render_device(mirt_scene* scene, const mirt_render_params* params, void* d_out, size_t d_out_bytes, void* hip_stream);
 size_t mirt_tile_buffer_bytes(const mirt_render_params* params);
+/* Gives back the workspace the scene holds for hip_stream (waits for the stream's frames first).  Call it before
+ * destroying a stream that has rendered with this scene; mirt_scene_destroy releases whatever is left.  No counterpart
+ * in the reference (it has no streams). */
+int mirt_release_stream(mirt_scene* scene, void* hip_stream);
 /* Counters of the most recent mirt_render_device call on this scene (synchronises hip_stream). */
 int mirt_get_stats(mirt_scene* scene, void* hip_stream, mirt_stats* stats);
 

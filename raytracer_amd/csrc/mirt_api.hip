@@ -77,10 +77,10 @@ struct DevBuf {
 };
 
 struct Workspace {
-	DevBuf hitO, hitD, hitN, shRes, active, pathDepth, litL, litS, counters, out;
+	DevBuf hitO, hitD, hitN, shRes, active, pathDepth, litL, litS, counters, out, ovf;
 	void release() {
 		hitO.release(); hitD.release(); hitN.release(); shRes.release(); active.release(); pathDepth.release();
-		litL.release(); litS.release(); counters.release(); out.release();
+		litL.release(); litS.release(); counters.release(); out.release(); ovf.release();
 	}
 };
 
@@ -159,7 +159,10 @@ struct mirt_scene {
 	int device = 0;
 	int numCUs = 256;
 	DScene ds;
-	DevBuf nodes, leafs, bvh, memb, tris, triX, triInfo, spheres, sphInfo, materials, lights, ovf, dbg;
+	DevBuf nodes, leafs, bvh, memb, tris, triX, triInfo, spheres, sphInfo, materials, lights, dbg;
+	DevBuf hookOvf;          // overflow area of the synchronous parity hooks (mirt_trace_rays, mirt_trace_primary_ids)
+	uint32_t ovfLevels = 0;  // traversal-stack entries a walk can need beyond the LDS part (0: none)
+	uint32_t ovfStride = 0;  // threads of a trace launch
 	bool nested = true;      // reference boxes nested: the primitive hierarchy may be used
 	uint32_t bvhDepth = 0;
 	bool deepBvh = false;    // hierarchy deeper than the LDS part of the traversal stack
@@ -272,8 +275,20 @@ int validate_desc(const mirt_scene_desc* d) {
 		for (int k = 0; k < 36; ++k)
 			if (!isfinite(f[k])) return fail(MIRT_E_INVALID, "sphere %u: non-finite centre, radius, transform or inverse transform (singular transform?)", i);
 	}
+	// Coordinates beyond 1e18: the hierarchy's quantised child boxes (scales up to 2^73 per step of a byte) could no longer
+	// enclose a node, and squared lengths overflow a float anyway.
 	for (uint64_t i = 0; i < (uint64_t)d->n_triangles * 9; ++i)
-		if (!isfinite(d->tri_verts[i])) return fail(MIRT_E_INVALID, "triangle %llu: non-finite vertex", (unsigned long long)(i / 9));
+		if (!(fabsf(d->tri_verts[i]) <= 1e18f)) return fail(MIRT_E_INVALID, "triangle %llu: vertex coordinate not finite or beyond 1e18", (unsigned long long)(i / 9));
+	for (uint32_t i = 0; i < d->n_spheres; ++i) {
+		const mirt_sphere& sp = d->spheres[i];
+		for (int k = 0; k < 3; ++k) {
+			const float ext = fabsf(sp.radius) * (fabsf(sp.M[0 * 4 + k]) + fabsf(sp.M[1 * 4 + k]) + fabsf(sp.M[2 * 4 + k]));
+			const float c = fabsf(sp.M[0 * 4 + k] * sp.center[0]) + fabsf(sp.M[1 * 4 + k] * sp.center[1]) + fabsf(sp.M[2 * 4 + k] * sp.center[2]) + fabsf(sp.M[3 * 4 + k]);
+			if (!(ext + c <= 1e18f)) return fail(MIRT_E_INVALID, "sphere %u: world-space extent beyond 1e18", i);
+		}
+	}
+	for (int k = 0; k < 3; ++k)
+		if (!(fabsf(d->camera.look_from[k]) <= 1e18f)) return fail(MIRT_E_INVALID, "camera position not finite or beyond 1e18");
 	for (uint32_t i = 0; i < d->n_prims; ++i)
 		if (d->prim_material[i] >= d->n_materials) return fail(MIRT_E_INVALID, "prim_material[%u] out of range", i);
 	return MIRT_OK;
@@ -461,7 +476,12 @@ int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 	if ((e = w.pathDepth.ensure(n))) return e;
 	if ((e = w.active.ensure(2 * n * 4))) return e;
 	if ((e = w.counters.ensure(CTR_COUNT * 4))) return e;
+	// the overflow part of the traversal stack is per stream, like everything else a launch writes: launches of frames
+	// on different streams run at the same time with identical grids
+	if (s->deepBvh && (e = w.ovf.ensure((size_t)s->ovfLevels * s->ovfStride * 4))) return e;
 	DFrame F;
+	F.ovf = (uint32_t*)w.ovf.p;
+	F.ovfStride = s->ovfStride;
 	F.hitO = (float4*)w.hitO.p; F.hitD = (float4*)w.hitD.p; F.hitN = (float4*)w.hitN.p;
 	F.shRes = (uint2*)w.shRes.p;
 	F.litL = (float4*)w.litL.p; F.litS = (float4*)w.litS.p;
@@ -919,17 +939,16 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	if (!e) e = upload(s->lights, lights.data(), lights.size() * 4);
 	if (!e) { e = s->dbg.ensure(16 * 8); if (!e) (void)hipMemset(s->dbg.p, 0, 16 * 8); }
 	ds.dbg = (unsigned long long*)s->dbg.p;
-	ds.ovf = nullptr;
-	ds.ovfStride = (uint32_t)s->numCUs * GRID_BLOCKS_PER_CU * BLOCK;
+	s->ovfStride = (uint32_t)s->numCUs * GRID_BLOCKS_PER_CU * BLOCK;
 	// the most entries a walk can hold: along any path, every node leaves behind all its children but one
 	const uint32_t stackNeed = bvhMaxStack + 1u;
 	s->diag[6] = stackNeed;
-	const uint32_t ldsEntries = s->refillMin < 64u ? STACK_LDS_REFILL : STACK_LDS; // see launch_frame: which k_trace variant runs
+	// Every kernel keeps at least this many entries in LDS (each variant its own number), so an area sized for the smaller
+	// number serves all of them, and a hierarchy that fits the smaller number needs no overflow variant anywhere.
+	const uint32_t ldsEntries = STACK_LDS_REFILL < STACK_LDS ? STACK_LDS_REFILL : STACK_LDS;
 	s->deepBvh = stackNeed > ldsEntries;
-	if (!e && s->deepBvh) {
-		e = s->ovf.ensure((size_t)(stackNeed - ldsEntries) * ds.ovfStride * 4);
-		ds.ovf = (uint32_t*)s->ovf.p;
-	}
+	s->ovfLevels = s->deepBvh ? stackNeed - ldsEntries : 0u;
+	if (!e && s->deepBvh) e = s->hookOvf.ensure((size_t)s->ovfLevels * s->ovfStride * 4);
 	if (!e && hipStreamCreate(&s->stream) != hipSuccess) e = fail(MIRT_E_DEVICE, "hipStreamCreate failed");
 	if (e) {
 		std::string keep = g_err;
@@ -956,11 +975,11 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 void mirt_scene_destroy(mirt_scene* s) {
 	if (!s) return;
 	(void)hipSetDevice(s->device);
-	if (s->stream) (void)hipStreamSynchronize(s->stream);
+	// the whole device, not stream by stream: a caller's stream may have been destroyed since its last frame
+	(void)hipDeviceSynchronize();
 	s->nodes.release(); s->leafs.release(); s->bvh.release(); s->memb.release(); s->tris.release(); s->triX.release(); s->triInfo.release();
-	s->spheres.release(); s->sphInfo.release(); s->materials.release(); s->lights.release(); s->ovf.release(); s->dbg.release();
+	s->spheres.release(); s->sphInfo.release(); s->materials.release(); s->lights.release(); s->hookOvf.release(); s->dbg.release();
 	for (FrameCtx* c : s->ctxs) {
-		(void)hipStreamSynchronize(c->stream);
 		c->ws.release();
 		if (c->ev0) (void)hipEventDestroy(c->ev0);
 		if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -969,6 +988,24 @@ void mirt_scene_destroy(mirt_scene* s) {
 	}
 	if (s->stream) (void)hipStreamDestroy(s->stream);
 	delete s;
+}
+
+int mirt_release_stream(mirt_scene* s, void* hip_stream) {
+	if (!s) return fail(MIRT_E_INVALID, "scene handle is NULL");
+	HIPCHK(hipSetDevice(s->device));
+	for (size_t i = 0; i < s->ctxs.size(); ++i) {
+		FrameCtx* c = s->ctxs[i];
+		if (c->stream != (hipStream_t)hip_stream) continue;
+		HIPCHK(hipStreamSynchronize(c->stream));
+		c->ws.release();
+		if (c->ev0) (void)hipEventDestroy(c->ev0);
+		if (c->ev1) (void)hipEventDestroy(c->ev1);
+		for (hipEvent_t e : c->launchEv) (void)hipEventDestroy(e);
+		delete c;
+		s->ctxs.erase(s->ctxs.begin() + (long)i);
+		return MIRT_OK;
+	}
+	return MIRT_OK; // no frame was ever issued on it: nothing is held
 }
 
 size_t mirt_tile_buffer_bytes(const mirt_render_params* p) {
@@ -995,7 +1032,7 @@ int mirt_scene_query(mirt_scene* s, uint32_t what, uint64_t* v) {
 	case MIRT_Q_MEMBERSHIP_ENTRIES: *v = s->memb.bytes / 32; break;
 	case MIRT_Q_DEVICE_BYTES:
 		*v = s->nodes.bytes + s->leafs.bytes + s->bvh.bytes + s->memb.bytes + s->tris.bytes + s->triX.bytes + s->triInfo.bytes + s->spheres.bytes + s->sphInfo.bytes +
-		     s->materials.bytes + s->lights.bytes + s->ovf.bytes;
+		     s->materials.bytes + s->lights.bytes + s->hookOvf.bytes;
 		break;
 	case MIRT_Q_TREE_WIDE_DEPTH: *v = s->wideDepth; break;
 	default:
@@ -1008,6 +1045,15 @@ int mirt_scene_query(mirt_scene* s, uint32_t what, uint64_t* v) {
 			HIPCHK(hipMemcpyFromSymbol(&x, HIP_SYMBOL(g_statFallback), 8));
 			HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_statFallback), &z, 8));
 			*v = x;
+			break;
+		}
+		if (what == 117 || what == 118) { // traversal-stack pushes: all / to the overflow area (read and clear)
+			unsigned long long x[2] = {0, 0}, z[2] = {0, 0};
+			HIPCHK(hipSetDevice(s->device));
+			HIPCHK(hipDeviceSynchronize());
+			HIPCHK(hipMemcpyFromSymbol(x, HIP_SYMBOL(g_statPush), 16));
+			if (what == 118) HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_statPush), z, 16));
+			*v = x[what - 117];
 			break;
 		}
 #endif
@@ -1124,7 +1170,7 @@ int mirt_trace_rays(mirt_scene* s, uint32_t trace_mode, uint64_t n, const float*
 	if (!e) {
 		const int grid = (int)((n + BLOCK - 1) / BLOCK < (uint64_t)s->numCUs * GRID_BLOCKS_PER_CU ? (n + BLOCK - 1) / BLOCK : (uint64_t)s->numCUs * GRID_BLOCKS_PER_CU);
 		const int mode = effective_mode(s, trace_mode);
-#define LAUNCH_LIST(M, O) hipLaunchKernelGGL((k_trace_list<M, O>), dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, n, (const float*)o.p, (const float*)d.p, (int32_t*)id.p, (float*)dist.p, (float*)nrm.p)
+#define LAUNCH_LIST(M, O) hipLaunchKernelGGL((k_trace_list<M, O>), dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, (uint32_t*)s->hookOvf.p, s->ovfStride, n, (const float*)o.p, (const float*)d.p, (int32_t*)id.p, (float*)dist.p, (float*)nrm.p)
 		if (mode == MODE_REFWALK) LAUNCH_LIST(MODE_REFWALK, false);
 		else if (mode == MODE_FAST) { if (s->deepBvh) LAUNCH_LIST(MODE_FAST, true); else LAUNCH_LIST(MODE_FAST, false); }
 		else { if (s->deepBvh) LAUNCH_LIST(MODE_EXACT, true); else LAUNCH_LIST(MODE_EXACT, false); }
@@ -1152,7 +1198,7 @@ int mirt_trace_primary_ids(mirt_scene* s, uint32_t trace_mode, uint32_t width, u
 	if (!e) {
 		const int grid = (int)((n + BLOCK - 1) / BLOCK < (uint64_t)s->numCUs * GRID_BLOCKS_PER_CU ? (n + BLOCK - 1) / BLOCK : (uint64_t)s->numCUs * GRID_BLOCKS_PER_CU);
 		const int mode = effective_mode(s, trace_mode);
-#define LAUNCH_IDS(M, O) hipLaunchKernelGGL((k_primary_ids<M, O>), dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, width, height, (int32_t*)id.p, (float*)dist.p)
+#define LAUNCH_IDS(M, O) hipLaunchKernelGGL((k_primary_ids<M, O>), dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, (uint32_t*)s->hookOvf.p, s->ovfStride, width, height, (int32_t*)id.p, (float*)dist.p)
 		if (mode == MODE_REFWALK) LAUNCH_IDS(MODE_REFWALK, false);
 		else if (mode == MODE_FAST) { if (s->deepBvh) LAUNCH_IDS(MODE_FAST, true); else LAUNCH_IDS(MODE_FAST, false); }
 		else { if (s->deepBvh) LAUNCH_IDS(MODE_EXACT, true); else LAUNCH_IDS(MODE_EXACT, false); }

@@ -66,10 +66,8 @@ struct DScene {
 	const uint4* sphInfo;
 	// (2) membership lists
 	const float4* memb;
-	// traversal stack overflow area (entries beyond the LDS part), [level][global thread]
-	uint32_t* ovf;
 	unsigned long long* dbg; // diagnostic event counters (MIRT_STATS builds)
-	uint32_t ovfStride;
+	uint32_t pad0;
 	uint32_t bvhRoot;
 	float bvhMin[3], bvhMax[3];
 	// (3) reference tree
@@ -105,6 +103,11 @@ struct DFrame {
 	float4* litL;      // [depth][slot] light sum of the hit at that depth
 	float4* litS;      // [depth][slot] mat.specular of that hit (weight of the next bounce)
 	uint32_t* counters; // see CTR_* below
+	// Traversal-stack overflow area (entries beyond the LDS part), [level][thread of the launch].  It belongs to the
+	// frame's workspace, one per stream: launches of frames on different streams run at the same time and every one of
+	// them indexes the area by its own block and thread numbers.
+	uint32_t* ovf;
+	uint32_t ovfStride; // threads of a trace launch
 	uint32_t nSlots;    // pixel slots in this launch (tiles x tile area)
 	uint32_t width, height;
 	uint32_t tileW, tileH, tilesX, nTilesLocal, firstTile, tileStride;

@@ -153,6 +153,7 @@ __device__ __forceinline__ bool box_hit(const RayCtx& r, const f3& e, f3 lo, f3 
 // underflow in either evaluation (host: E = NaN; here: |q|_1 >= 1e10), run the reference's operations as they stand.
 #if MIRT_STATS
 __device__ unsigned long long g_statFallback[1];
+__device__ unsigned long long g_statPush[2]; // traversal-stack pushes: all, and those that went to the global overflow area
 #endif
 template <int MODE>
 __device__ __forceinline__ float tri_hit(const RayCtx& r, const float4* __restrict__ T, const float4* __restrict__ X, float tcull) {
@@ -405,6 +406,10 @@ struct LdsStack {
 	// The overflow accesses are written as inline asm on purpose: given two plain loads, one from LDS and one from global
 	// memory, the compiler merges them into a single FLAT load through a selected pointer, which makes every pop slow.
 	__device__ __forceinline__ void push(int sp, uint32_t v) {
+#if MIRT_STATS
+		atomicAdd(g_statPush, 1ull);
+		if (OVF && sp >= NLDS) atomicAdd(g_statPush + 1, 1ull);
+#endif
 		if (!OVF || sp < NLDS) lds[sp * BLOCK] = v;
 		else {
 			uint32_t* p = ovf + (size_t)(sp - NLDS) * ovfStride;
@@ -817,11 +822,11 @@ __device__ __forceinline__ bool item_ray(const DScene& S, const DFrame& F, const
 		// are left out of shadow_rays_traced.
 		if (S.shadowCull && F.debug == D_NONE) {
 			const f3 N = F3(F.hitN[T.rd + slot]);
-			const bool kd0 = !(F.features & F_DIFFUSE) || !(dot3(normalize3(N), normalize3(L)) > 0.0f);  // fmaxf(x, 0) == 0
+			const bool kd0 = !(F.features & F_DIFFUSE) || dot3(normalize3(N), normalize3(L)) <= 0.0f;    // std::max(x, 0.0f) is a zero; a NaN is not
 			bool ks0 = !(F.features & F_SPECULAR);
 			if (!ks0) {
 				const f3 H = normalize3(d + normalize3(po - o));      // main.cpp:226-227
-				ks0 = !(dot3(H, N) > 0.0f);                           // pow(0, shininess > 0) == 0
+				ks0 = dot3(H, N) <= 0.0f;                             // pow(0, shininess > 0) == 0; a NaN stays a NaN
 			}
 			const float atten = ll.w > 0.0f ? 1.0f / (S.atten[0] + S.atten[1] * dl + S.atten[2] * (dl * dl)) : 1.0f; // :266-268
 			if (kd0 && ks0 && fabsf(atten) <= 1e15f) {
@@ -882,8 +887,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == M
 	__shared__ uint32_t s_list[BLOCK / WAVE][256];
 	LdsStack<OVF, NLDS> stk;
 	stk.lds = s_stack + threadIdx.x;
-	stk.ovf = OVF ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
-	stk.ovfStride = S.ovfStride;
+	stk.ovf = OVF ? F.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
+	stk.ovfStride = F.ovfStride;
 	const int lane = threadIdx.x & 63;
 	const unsigned long long ltMask = (1ull << lane) - 1ull;
 	// hit records: read those of depth-1, write those of depth
@@ -1029,11 +1034,14 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, DFrame F, int depth) 
 				lit = (occRef == REF_NONE) || (F.debug == D_SHADOW_MAP && __uint_as_float(res.y) >= length3(L));
 			}
 			if (lit) {
-				const float kd = fmaxf(dot3(normalize3(N), normalize3(L)), 0.0f);   // :225, :258-260
+				// std::max(x, 0.0f) is (x < 0.0f) ? 0.0f : x: a NaN (zero-length L or N) stays a NaN, fmaxf would drop it
+				const float kdRaw = dot3(normalize3(N), normalize3(L));
+				const float kd = (kdRaw < 0.0f) ? 0.0f : kdRaw;                      // :225, :258-260
 				const f3 eye = o - P;                                                // :226
 				const f3 H = normalize3(Ln + normalize3(eye));                       // :227
 				// :262-264 powf; evaluated in double and rounded once, which reproduces a correctly rounded powf
-				const float ks = (float)pow((double)fmaxf(dot3(H, N), 0.0f), (double)shininess);
+				const float ksRaw = dot3(H, N);
+				const float ks = (float)pow((double)((ksRaw < 0.0f) ? 0.0f : ksRaw), (double)shininess);
 				if (F.debug == D_DIFFUSE_INTENSITY) sum = sum + F3(kd, kd, kd);
 				else if (F.debug == D_SPECULAR_INTENSITY) sum = sum + F3(ks, ks, ks);
 				else if (F.debug == D_NORMAL_MAP) sum = sum + N;
@@ -1087,13 +1095,13 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DFrame F, uint8_t* __restrict
 
 // ---- narrow seam: closest hit for a list of rays ----------------------------------------------------------------------
 template <int MODE, bool OVF>
-__global__ __launch_bounds__(BLOCK) void k_trace_list(DScene S, uint64_t n, const float* __restrict__ o3, const float* __restrict__ d3,
+__global__ __launch_bounds__(BLOCK) void k_trace_list(DScene S, uint32_t* ovf, uint32_t ovfStride, uint64_t n, const float* __restrict__ o3, const float* __restrict__ d3,
                                                       int32_t* __restrict__ primId, float* __restrict__ dist, float* __restrict__ normal) {
 	__shared__ uint32_t s_stack[MODE == MODE_REFWALK ? 1 : STACK_LDS * BLOCK];
 	LdsStack<OVF> stk;
 	stk.lds = s_stack + (MODE == MODE_REFWALK ? 0 : threadIdx.x);
-	stk.ovf = OVF ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
-	stk.ovfStride = S.ovfStride;
+	stk.ovf = OVF ? ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
+	stk.ovfStride = ovfStride;
 	for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
 		const f3 o = F3(o3 + 3 * i), d = F3(d3 + 3 * i);
 		const RayCtx r = make_ray(o, d);
@@ -1116,12 +1124,12 @@ __global__ __launch_bounds__(BLOCK) void k_trace_list(DScene S, uint64_t n, cons
 }
 
 template <int MODE, bool OVF>
-__global__ __launch_bounds__(BLOCK) void k_primary_ids(DScene S, uint32_t width, uint32_t height, int32_t* __restrict__ primId, float* __restrict__ dist) {
+__global__ __launch_bounds__(BLOCK) void k_primary_ids(DScene S, uint32_t* ovf, uint32_t ovfStride, uint32_t width, uint32_t height, int32_t* __restrict__ primId, float* __restrict__ dist) {
 	__shared__ uint32_t s_stack[MODE == MODE_REFWALK ? 1 : STACK_LDS * BLOCK];
 	LdsStack<OVF> stk;
 	stk.lds = s_stack + (MODE == MODE_REFWALK ? 0 : threadIdx.x);
-	stk.ovf = OVF ? S.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
-	stk.ovfStride = S.ovfStride;
+	stk.ovf = OVF ? ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
+	stk.ovfStride = ovfStride;
 	const uint64_t n = (uint64_t)width * height;
 	for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
 		f3 o, d;

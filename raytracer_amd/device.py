@@ -23,8 +23,8 @@ class DeviceScene:
     """A scene resident in one GPU's HBM (mirt_scene handle).  The equivalent of the reference's
     `Scene scene(path)` object once loading has finished (RayTracer/main.cpp:107)."""
 
-    def __init__(self, flat_scene, device=0):
-        self.lib = _capi.load_library()
+    def __init__(self, flat_scene, device=0, lib=None):
+        self.lib = lib or _capi.load_library()  # lib: another build of the same ABI (tests: small-stack and statistics builds)
         self.flat = flat_scene
         self.device = device
         d = flat_scene.desc()
@@ -67,6 +67,9 @@ class DeviceScene:
 
     def render_device(self, params, d_out_ptr, d_out_bytes, stream_ptr=0):
         _check(self.lib, self.lib.mirt_render_device(self.h, C.byref(params), C.c_void_p(d_out_ptr), d_out_bytes, C.c_void_p(stream_ptr)))
+
+    def release_stream(self, stream_ptr):
+        _check(self.lib, self.lib.mirt_release_stream(self.h, C.c_void_p(stream_ptr)))
 
     def stats(self, stream_ptr=0):
         st = Stats()

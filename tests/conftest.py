@@ -9,6 +9,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (read once, when HIP initialises) and streams that
+# share a queue run one after the other: the multi-stream tests want their eight streams to really overlap.
+if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 16:
+    os.environ["GPU_MAX_HW_QUEUES"] = "16"
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 SCENE_NAMES = ["scene1", "scene2", "scene3", "scene4-specular", "scene5", "scene6", "scene7"]
 
