@@ -226,6 +226,11 @@ int mirt_trace_rays(mirt_scene* scene, uint32_t trace_mode, uint64_t n, const fl
 /* Parity hook: nearest hit of every primary ray (Camera::createRayToPixel(j+0.5, i+0.5), main.cpp:152). */
 int mirt_trace_primary_ids(mirt_scene* scene, uint32_t trace_mode, uint32_t width, uint32_t height, int32_t* prim_id_out, float* dist_out);
 
+/* Parity hook: out[k] = the device's evaluation of glm::pow(x[k], y[k]) as calculateSpecularLighting uses it
+ * (main.cpp:262-264), i.e. the powf of the C library the reference is linked against, restated on the device.
+ * Host arrays. */
+int mirt_test_powf(int device, uint64_t n, const float* x, const float* y, float* out);
+
 const char* mirt_last_error(void);
 
 #ifdef __cplusplus

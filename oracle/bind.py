@@ -130,7 +130,10 @@ class RefOracle:
         spans = [(row0, row1)] if row_step == 1 else [(r, r + 1) for r in range(row0, row1, row_step)]
         for a, b in spans:
             rays = np.zeros(3, np.uint64)
-            secs += self.L.ref_render_rows(self.h, features, debug, w, h, a, b, col_step, bgr.ctypes.data, rays.ctypes.data)
+            t = self.L.ref_render_rows(self.h, features, debug, w, h, a, b, col_step, bgr.ctypes.data, rays.ctypes.data)
+            if t < 0:
+                raise AssertionError("rows [%d,%d): the restated shading driver (ray counts) and the reference's own text disagree on a byte" % (a, b))
+            secs += t
             tot += rays
         return bgr, dict(primary=int(tot[0]), shadow=int(tot[1]), reflection=int(tot[2]), seconds=secs)
 

@@ -5,12 +5,13 @@
 // oracle/Makefile into oracle/_ref/libref_oracle.so.  The harness adds no arithmetic of its own to
 // the intersection / traversal / camera / quantisation code: it calls the reference's functions.
 //
-// The one part that cannot be taken from the reference as compiled code is the shading driver
-// (computePixelColor / calculateLightingColor, RayTracer/main.cpp:176-268): main.cpp includes
-// <windows.h> and "Shlwapi.h", which this image does not have, so main.cpp is unbuildable here.
-// Those ~90 lines are restated below (shade_* functions) on top of the reference's own Color,
-// Camera::createPointFromRay, Scene::findClosestIntersection and GLM; the restated part is marked
-// "restated" and each step cites the main.cpp line it follows.
+// The shading driver (computePixelColor / calculateLightingColor, RayTracer/main.cpp:176-268) lives in
+// main.cpp, which as a file is unbuildable here (it includes <windows.h> and "Shlwapi.h").  The driver itself
+// needs neither, so the build recipe (oracle/Makefile) cuts exactly those lines out of main.cpp, unchanged, into
+// two include files that are compiled below inside namespace reftext: every pixel ref_render_rows returns is
+// computed by the reference's own text.  The reference does not count rays; the counts come from a restated copy
+// of the same ~90 lines (shadeRay / shadeLights, each step citing the main.cpp line it follows), which is run
+// beside the reference's text on request and must then produce the same bytes.
 //
 // Private members (Partition::root, Scene::objectTree, Sphere::center, ...) are reached by
 // redefining the access keywords in this translation unit only; class layout is unchanged.
@@ -41,6 +42,14 @@
 #include "Scene.h"
 #undef private
 #undef protected
+
+// ---- the reference's own text: main.cpp:24-42 | 57-59, 65-66, 69-73, 176-268, 287-293 -----------------------------
+namespace reftext {
+#include "main_enums.inc"
+int featureFlags = 15;            // main.cpp:91, set per call by ref_render_rows
+Debug debugFlag = Debug::NONE;    // main.cpp:92
+#include "main_shading.inc"
+}  // namespace reftext
 
 namespace {
 
@@ -102,7 +111,7 @@ IdHit mirrorTraverse(const Ray& ray, const PNode* node, Counted* cnt) {
 	return r;
 }
 
-// ---- restated from RayTracer/main.cpp (unbuildable here: needs windows.h / Shlwapi.h) ----------
+// ---- restated from RayTracer/main.cpp:176-268, with ray counters (the pixels come from reftext above) ----------
 
 Color scaleColor(float x, const Color& c) { return c * x; }  // main.cpp:57-59
 
@@ -369,28 +378,45 @@ void ref_box_intersect(const float* bmin, const float* bmax, int64_t n, const fl
 	}
 }
 
-// ---- pixel loop (main.cpp:137-157) over rows [row0,row1), shading restated as described at the top ----
-// bgr: full-image buffer (w*h*3), only the requested rows are written.  rayCounts[3] = primary, shadow, reflection.
-// Returns seconds spent in the loop (steady_clock), excluding scene load.
+// ---- pixel loop (main.cpp:137-157) over rows [row0,row1) ----
+// Every pixel is computed by the reference's own computePixelColor (reftext, see the top); the loop header and the
+// three stores restate main.cpp:137-138, 152-156.  bgr: full-image buffer (w*h*3), only the requested rows are
+// written.  Returns seconds spent in that loop (steady_clock), excluding scene load.
+// rayCounts (may be NULL) = primary, shadow, reflection: the reference keeps no such counts, so when they are asked for
+// the rows are rendered a second time, outside the timed region, by the restated driver with counters; its bytes must
+// equal the reference text's, otherwise the call returns -1.
 double ref_render_rows(void* h, int features, int debug, int w, int hgt, int row0, int row1, int colStep, uint8_t* bgr, uint64_t* rayCounts) {
 	RefScene* rs = (RefScene*)h;
-	ShadeCtx cx; cx.scene = rs->scene; cx.features = features; cx.debug = debug; cx.primary = cx.shadow = cx.reflection = 0;
+	const Scene& scene = *rs->scene;
 	Camera cam = rs->scene->getCamera();  // main.cpp:129
 	if (colStep < 1) colStep = 1;
+	reftext::featureFlags = features;
+	reftext::debugFlag = (reftext::Debug)debug;
 	auto t0 = std::chrono::steady_clock::now();
 	for (int i = row0; i < row1; ++i) {
 		for (int j = 0; j < w; j += colStep) {
 			Ray ray = cam.createRayToPixel(j + 0.5f, i + 0.5f, w, hgt);  // main.cpp:152
-			cx.primary++;
-			Color c = shadeRay(cx, ray, 0);  // main.cpp:153
+			Color c = reftext::computePixelColor(ray, scene, 0);  // main.cpp:153
 			size_t k = ((size_t)i * w + j) * 3;
-			bgr[k] = (uint8_t)c.getB();  // main.cpp:154-156
-			bgr[k + 1] = (uint8_t)c.getG();
-			bgr[k + 2] = (uint8_t)c.getR();
+			bgr[k] = c.getB();  // main.cpp:154-156
+			bgr[k + 1] = c.getG();
+			bgr[k + 2] = c.getR();
 		}
 	}
 	auto t1 = std::chrono::steady_clock::now();
-	if (rayCounts) { rayCounts[0] = cx.primary; rayCounts[1] = cx.shadow; rayCounts[2] = cx.reflection; }
+	if (rayCounts) {
+		ShadeCtx cx; cx.scene = rs->scene; cx.features = features; cx.debug = debug; cx.primary = cx.shadow = cx.reflection = 0;
+		for (int i = row0; i < row1; ++i) {
+			for (int j = 0; j < w; j += colStep) {
+				Ray ray = cam.createRayToPixel(j + 0.5f, i + 0.5f, w, hgt);
+				cx.primary++;
+				Color c = shadeRay(cx, ray, 0);
+				size_t k = ((size_t)i * w + j) * 3;
+				if (bgr[k] != (uint8_t)c.getB() || bgr[k + 1] != (uint8_t)c.getG() || bgr[k + 2] != (uint8_t)c.getR()) return -1.0;
+			}
+		}
+		rayCounts[0] = cx.primary; rayCounts[1] = cx.shadow; rayCounts[2] = cx.reflection;
+	}
 	return std::chrono::duration<double>(t1 - t0).count();
 }
 

@@ -97,6 +97,7 @@ SYMBOLS = [
     ("mirt_assemble_tiles", C.c_int, [C.c_int, C.POINTER(RenderParams), C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     ("mirt_trace_rays", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mirt_trace_primary_ids", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("mirt_test_powf", C.c_int, [C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mirt_last_error", C.c_char_p, []),
     # include/mirt_host.h
     ("mirt_host_scene_load", C.c_int, [C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]),

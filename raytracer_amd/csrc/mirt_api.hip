@@ -864,7 +864,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		const mirt_sphere& sp = d->spheres[i];
 		float* t = sph.data() + (size_t)ni * SPHERE_F4 * 4;
 		t[0] = sp.center[0]; t[1] = sp.center[1]; t[2] = sp.center[2];
-		t[3] = powf(sp.radius, 2.0f);                                // Sphere.cpp:64 glm::pow(float,float)
+		t[3] = sp.radius * sp.radius;                                // Sphere.cpp:64 glm::pow(radius, 2.0f): g++ folds the constant exponent 2 into a multiplication
 		memcpy(t + 4, sp.M, 64);
 		memcpy(t + 20, sp.Minv, 64);
 		const uint32_t prim = d->sphere_prim[i];
@@ -1183,6 +1183,26 @@ int mirt_trace_rays(mirt_scene* s, uint32_t trace_mode, uint64_t n, const float*
 		if (he != hipSuccess) e = fail(MIRT_E_DEVICE, "mirt_trace_rays: %s", hipGetErrorString(he));
 	}
 	o.release(); d.release(); id.release(); dist.release(); nrm.release();
+	return e;
+}
+
+int mirt_test_powf(int device, uint64_t n, const float* x, const float* y, float* out) {
+	if (n == 0) return MIRT_OK;
+	if (!x || !y || !out) return fail(MIRT_E_INVALID, "NULL array");
+	HIPCHK(hipSetDevice(device));
+	DevBuf dx, dy, dout;
+	int e = upload(dx, x, n * 4);
+	if (!e) e = upload(dy, y, n * 4);
+	if (!e) e = dout.ensure(n * 4);
+	if (!e) {
+		const int grid = (int)((n + BLOCK - 1) / BLOCK < 4096 ? (n + BLOCK - 1) / BLOCK : 4096);
+		hipLaunchKernelGGL(k_test_powf, dim3(grid), dim3(BLOCK), 0, nullptr, n, (const float*)dx.p, (const float*)dy.p, (float*)dout.p);
+		hipError_t he = hipGetLastError();
+		if (he == hipSuccess) he = hipDeviceSynchronize();
+		if (he == hipSuccess) he = hipMemcpy(out, dout.p, n * 4, hipMemcpyDeviceToHost);
+		if (he != hipSuccess) e = fail(MIRT_E_DEVICE, "mirt_test_powf: %s", hipGetErrorString(he));
+	}
+	dx.release(); dy.release(); dout.release();
 	return e;
 }
 

@@ -13,6 +13,7 @@
 //   shading             computePixelColor, calculateLightingColor RayTracer/main.cpp:176-268
 //   quantisation        Color::getR/G/B                           RayTracer/Color.cpp:13-23
 #include "mirt_device.h"
+#include "mirt_powf.h"
 
 #pragma clang fp contract(off)
 
@@ -66,6 +67,15 @@ __device__ __forceinline__ f3 cross3(f3 a, f3 b) { return F3(a.y * b.z - b.y * a
 __device__ __forceinline__ float inv_sqrt(float x) { return 1.0f / sqrtf(x); }
 __device__ __forceinline__ f3 normalize3(f3 a) { return a * inv_sqrt(dot3(a, a)); }
 __device__ __forceinline__ float length3(f3 a) { return sqrtf(dot3(a, a)); }
+
+// glm::pow(float, float) = powf of the C library the reference is linked against (main.cpp:263): glibc's powf, restated
+// bit for bit in mirt_powf.h for positive finite bases; zeros, NaNs, infinities and overflow have exact IEEE answers, which
+// the generic double-precision pow gives after one rounding to float.
+__device__ __forceinline__ float ref_powf(float x, float y) {
+	float r;
+	if (mirt_powf::powf_glibc(x, y, r)) return r;
+	return (float)pow((double)x, (double)y);
+}
 
 struct Hit {
 	float dist;   // world distance |P - o| (Intersection::distAlongRay); +inf = miss
@@ -1018,7 +1028,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, DFrame F, int depth) 
 			if (ll.w > 0.0f) {                                              // :213
 				L = F3(ll) - P;                                             // :214
 				const float dl = length3(L);                                // :215
-				atten = 1.0f / (S.atten[0] + S.atten[1] * dl + S.atten[2] * (dl * dl)); // :266-268
+				// :266-268; glm::pow(distance, 2.0f) is dl * dl in the reference's build: g++ folds a power with the
+				// constant exponent 2 into a multiplication (one mulss in the machine code of calculateAttenuation)
+				atten = 1.0f / (S.atten[0] + S.atten[1] * dl + S.atten[2] * (dl * dl));
 			}
 			else {
 				L = F3(ll);                                                 // :219
@@ -1039,9 +1051,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, DFrame F, int depth) 
 				const float kd = (kdRaw < 0.0f) ? 0.0f : kdRaw;                      // :225, :258-260
 				const f3 eye = o - P;                                                // :226
 				const f3 H = normalize3(Ln + normalize3(eye));                       // :227
-				// :262-264 powf; evaluated in double and rounded once, which reproduces a correctly rounded powf
 				const float ksRaw = dot3(H, N);
-				const float ks = (float)pow((double)((ksRaw < 0.0f) ? 0.0f : ksRaw), (double)shininess);
+				const float ks = ref_powf((ksRaw < 0.0f) ? 0.0f : ksRaw, shininess);   // :262-264
 				if (F.debug == D_DIFFUSE_INTENSITY) sum = sum + F3(kd, kd, kd);
 				else if (F.debug == D_SPECULAR_INTENSITY) sum = sum + F3(ks, ks, ks);
 				else if (F.debug == D_NORMAL_MAP) sum = sum + N;
@@ -1139,6 +1150,11 @@ __global__ __launch_bounds__(BLOCK) void k_primary_ids(DScene S, uint32_t* ovf, 
 		primId[i] = h.ref != REF_NONE ? (int32_t)info_of(S, h.ref).x : -1;
 		dist[i] = h.ref != REF_NONE ? h.dist : __builtin_inff();
 	}
+}
+
+// ---- parity hook: the device's powf for a list of arguments ----------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_test_powf(uint64_t n, const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out) {
+	for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) out[i] = ref_powf(x[i], y[i]);
 }
 
 // ---- multi-GPU: put gathered per-rank tile buffers back into one image --------------------------------------------------

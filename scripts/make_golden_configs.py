@@ -87,6 +87,20 @@ def main(which):
             rows = np.linspace(h * 0.15, h * 0.85, 16).astype(np.int64)
             g["rows_" + tag] = rows
             g["bgr_rows_" + tag], g["rays_rows_" + tag] = rows_of(ref, w, h, rows)
+            # ray counts of the 8-row bands the rows lie in (a band is what the device can render by itself: tiles are
+            # multiples of 8 pixels high)
+            bands = np.zeros((len(rows), 3), np.uint64)
+            for k, r in enumerate(rows):
+                b0 = int(r) // 8 * 8
+                _, st = ref.render(w, h, row0=b0, row1=min(b0 + 8, h))
+                bands[k] = [st["primary"], st["shadow"], st["reflection"]]
+            g["rays_bands_" + tag] = bands
+            # nearest-hit primitive and distance of the primary rays of the same rows
+            o, d = ref.primary_rays(w, h)
+            sel = (rows[:, None] * w + np.arange(w)[None, :]).reshape(-1)
+            ids, dist, _, _ = ref.trace(o[sel], d[sel], want_normals=False)
+            del o, d
+            g["prim_id_rows_" + tag], g["dist_rows_" + tag] = ids.reshape(len(rows), w), dist.reshape(len(rows), w)
             print("c3", tag, g["rays_rows_" + tag].tolist(), flush=True)
         np.savez_compressed(os.path.join(OUT, "c3_dragon.golden.npz"), **g)
         ref.close()

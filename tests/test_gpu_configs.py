@@ -62,6 +62,21 @@ def test_c3_c4_dragon_rows_of_the_full_size_image(tag, w, h, goldens):
         rows = g["rows_" + tag]
         assert np.array_equal(img[rows], g["bgr_rows_" + tag])
         assert st["primary_rays"] == w * h
+        # nearest-hit primitive and distance bits of every primary ray of those rows
+        ids, dist = s.trace_primary_ids(w, h)
+        assert np.array_equal(ids.reshape(h, w)[rows], g["prim_id_rows_" + tag])
+        assert np.array_equal(bits(dist).reshape(h, w)[rows], bits(g["dist_rows_" + tag]))
+        # ray counts: the device renders tiles (multiples of 8 rows), so the 8-row band around each golden row is rendered
+        # tile by tile (1024x8 tiles, one tile per call) and its counts compared with the reference's for the same band
+        tiles_x = (w + 1023) // 1024
+        n_tiles = tiles_x * ((h + 7) // 8)
+        for r, want in zip(rows, g["rays_bands_" + tag]):
+            got = np.zeros(3, np.uint64)
+            for tx in range(tiles_x):
+                _, bst = s.render(w, h, out=img, tile_w=1024, tile_h=8, first_tile=(int(r) // 8) * tiles_x + tx, tile_stride=n_tiles)
+                got += np.array(_rays(bst), np.uint64)
+            assert got.tolist() == want.tolist(), (tag, int(r))
+        assert np.array_equal(img[rows], g["bgr_rows_" + tag])  # the tile renders wrote the same bytes into the image
         if tag == "4k":
             ref_img, _ = s.render(w, h, trace_mode=_capi.TRACE_REFWALK)
             assert np.array_equal(ref_img, img)

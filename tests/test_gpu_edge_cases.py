@@ -44,3 +44,18 @@ def test_singular_sphere_transform_is_rejected():
     fs = FlatScene.from_text("size 32 32\n" + HEAD + "point 0 2 2 1 1 1\npushTransform\nscale 1 0 1\nsphere 0 0 0 1\npopTransform\n")
     with pytest.raises(MirtError, match="singular"):
         DeviceScene(fs, 0)
+
+
+def test_device_powf_is_the_reference_builds_powf(goldens):
+    """calculateSpecularLighting (main.cpp:262-264): the device's powf against the committed outputs of the C library the
+    reference build links against (NaN results compared as NaN)."""
+    import ctypes as C
+    from raytracer_amd import _capi
+    lib = _capi.load_library()
+    g = goldens("kat_powf")
+    x, y, want = (np.ascontiguousarray(g[k], np.float32) for k in ("x", "y", "want"))
+    got = np.zeros_like(want)
+    assert lib.mirt_test_powf(0, x.size, x.ctypes.data, y.ctypes.data, got.ctypes.data) == 0
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(got[~nan].view(np.uint32), want[~nan].view(np.uint32))
