@@ -184,6 +184,18 @@ int mirt_render(mirt_scene* scene, const mirt_render_params* params, uint8_t* bg
  * a queue do not overlap: give the process at least as many queues as frames in flight. */
 int mirt_render_device(mirt_scene* scene, const mirt_render_params* params, void* d_out, size_t d_out_bytes, void* hip_stream);
 size_t mirt_tile_buffer_bytes(const mirt_render_params* params);
+
+/* mirt_render_device for callers that cannot allocate device memory: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same arguments, same output bytes
+ * as mirt_render_device, but the frame's working memory (hit records, lists, counters, the overflow part of the
+ * traversal stack) is a fixed array of MIRT_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds from the
+ * moment the library is loaded; the call allocates and frees nothing (no hipMalloc/hipFree, no events, no host
+ * containers) and keeps no per-stream state, so mirt_get_stats and mirt_get_launch_times do not see its frames.
+ * A frame that needs more than the array holds (the message says how much: about 100 + 8*lights + 32*(maxdepth+1)
+ * bytes per pixel slot) is refused with MIRT_E_INVALID.  All calls on one GPU share that GPU's array: calls whose
+ * frames overlap in time on one GPU -- different streams, different scenes, different host threads -- race. */
+#define MIRT_NOALLOC_SCRATCH_BYTES (256u << 20)
+int mirt_render_device_noalloc(mirt_scene* scene, const mirt_render_params* params, void* d_out, size_t d_out_bytes, void* hip_stream);
 /* Gives back the workspace the scene holds for hip_stream (waits for the stream's frames first).  Call it before
  * destroying a stream that has rendered with this scene; mirt_scene_destroy releases whatever is left.  No counterpart
  * in the reference (it has no streams). */

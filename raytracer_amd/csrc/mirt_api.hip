@@ -155,6 +155,15 @@ struct FrameCtx {
 	uint32_t nLaunches = 0;
 };
 
+// ---- scratch of the entry point that allocates nothing (mirt_render_device_noalloc) ------------------------------------------
+// One file-scope array per GPU (every device the code object is loaded on holds its own copy until the process ends); it
+// takes the place of the per-stream workspace.  `scratch` below is only the host-side handle of the symbol: the device
+// address is looked up once per device, with that device current (scratch_init, called from mirt_scene_create), and only
+// that address is ever given to kernels, memsets or copies.
+static __device__ __align__(256) unsigned char scratch[MIRT_NOALLOC_SCRATCH_BYTES];
+#define MIRT_MAX_DEVICES 64
+static unsigned char* g_scratchPtr[MIRT_MAX_DEVICES];
+
 struct mirt_scene {
 	int device = 0;
 	int numCUs = 256;
@@ -354,6 +363,16 @@ FrameCtx* ctx_for(mirt_scene* s, hipStream_t st, bool create) {
 	return c;
 }
 
+// set-up, once per device: the device address of `scratch` on the device that is current
+int scratch_init(int device) {
+	if (device < 0 || device >= MIRT_MAX_DEVICES) return MIRT_OK; // such a device simply has no allocation-free entry point
+	if (g_scratchPtr[device]) return MIRT_OK;
+	void* ptr = nullptr;
+	HIPCHK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+	g_scratchPtr[device] = (unsigned char*)ptr;
+	return MIRT_OK;
+}
+
 // fn(i) for every i < n on up to 16 threads; the iterations must not depend on each other
 template <class F>
 void parallel_for(uint32_t n, F fn) {
@@ -375,7 +394,7 @@ int effective_mode(const mirt_scene* s, uint32_t mode) { return s->nested ? (int
 
 // event after launch i (event 0 precedes the first launch); only when profiling is on
 void mark(mirt_scene* s, FrameCtx* c, hipStream_t st, int kind) {
-	if (!s->profiling) return;
+	if (!c || !s->profiling) return;
 	const size_t need = (size_t)c->nLaunches + 2;
 	while (c->launchEv.size() < need) {
 		hipEvent_t e = nullptr;
@@ -397,7 +416,7 @@ void launch_frame(mirt_scene* s, FrameCtx* c, const DFrame& F, uint8_t* out, hip
 	const int grid = s->numCUs * GRID_BLOCKS_PER_CU;
 	const int sgrid = s->numCUs * 8;
 	int launch = 0;
-	c->nLaunches = 0;
+	if (c) c->nLaunches = 0;
 	mark(s, c, st, -1);
 #ifdef MIRT_ALWAYS_REFILL
 	const bool refill = MODE != MODE_REFWALK;
@@ -441,53 +460,53 @@ FastDiv make_div(uint32_t d) {
 	return f;
 }
 
-int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t d_out_bytes, hipStream_t st, bool packed) {
-	uint32_t tileW, tileH;
+// Device memory of one frame beyond its output: the arrays of DFrame, in this order.
+enum { WS_HITO, WS_HITD, WS_HITN, WS_SHRES, WS_LITL, WS_LITS, WS_PATHDEPTH, WS_ACTIVE, WS_COUNTERS, WS_OVF, WS_N };
+struct FrameLayout {
+	size_t bytes[WS_N];
+};
+FrameLayout frame_layout(const mirt_scene* s, size_t n) {
+	const size_t depths = (size_t)s->maxDepth + 1, nl = s->nLights;
+	FrameLayout L;
+	L.bytes[WS_HITO] = L.bytes[WS_HITD] = L.bytes[WS_HITN] = 2 * n * 16;
+	L.bytes[WS_SHRES] = (nl ? n * nl : 1) * 8;
+	L.bytes[WS_LITL] = L.bytes[WS_LITS] = depths * n * 16;
+	L.bytes[WS_PATHDEPTH] = n;
+	L.bytes[WS_ACTIVE] = 2 * n * 4;
+	L.bytes[WS_COUNTERS] = CTR_COUNT * 4;
+	// the overflow part of the traversal stack belongs to the frame like everything else a launch writes: launches of
+	// frames on different streams run at the same time with identical grids
+	L.bytes[WS_OVF] = s->deepBvh ? (size_t)s->ovfLevels * s->ovfStride * 4 : 0;
+	return L;
+}
+
+// Checks shared by every way of rendering a frame.  *empty: nothing to launch (no slots).
+int frame_checks(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t d_out_bytes, bool packed, uint32_t& tileW, uint32_t& tileH, TileGeom& g, size_t& need) {
 	int e = check_params(s, p, tileW, tileH);
 	if (e) return e;
 	if (!d_out) return fail(MIRT_E_INVALID, "output buffer is NULL");
-	const TileGeom g = tile_geom(p, tileW, tileH);
-	const size_t need = packed ? (size_t)g.nSlots * 3 : (size_t)p->width * p->height * 3;
+	g = tile_geom(p, tileW, tileH);
+	need = packed ? (size_t)g.nSlots * 3 : (size_t)p->width * p->height * 3;
 	if (d_out_bytes < need) return fail(MIRT_E_INVALID, "output buffer holds %zu bytes, %zu needed", d_out_bytes, need);
 	if (g.nSlots >= 0xffffffc0ull) return fail(MIRT_E_INVALID, "too many pixel slots for one launch");
-	HIPCHK(hipSetDevice(s->device));
-	FrameCtx* c = ctx_for(s, st, true);
-	if (!c) return MIRT_E_INVALID;
-	c->lastValid = false;
-	if (g.nSlots == 0) { c->lastPrimary = 0; c->lastFeatures = p->feature_bits; return MIRT_OK; }
-	if (s->maxDepth < 0) {
-		// depth 0 already exceeds maxDepth: computePixelColor returns Color() for every pixel (main.cpp:177,199)
-		HIPCHK(hipMemsetAsync(d_out, 0, need, st));
-		c->lastPrimary = g.livePixels; // the camera ray of every pixel is still made (main.cpp:152)
-		c->lastFeatures = p->feature_bits;
-		return MIRT_OK;
-	}
-	Workspace& w = c->ws;
+	if ((size_t)g.nSlots * ((size_t)s->nLights + 1) >= 0xffffffffull) return fail(MIRT_E_INVALID, "too many rays per depth for one launch (%llu slots x %u lights)", (unsigned long long)g.nSlots, s->nLights);
+	return MIRT_OK;
+}
+
+// Puts one frame on the stream: clears, every launch of the frame.  mem[] are the arrays of frame_layout(); c may be NULL
+// (no per-launch profiling then).  Allocates nothing.
+int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const TileGeom& g, uint32_t tileW, uint32_t tileH, bool packed,
+                  void* const mem[WS_N], void* d_out, size_t need, hipStream_t st) {
 	const size_t n = (size_t)g.nSlots;
-	const size_t depths = (size_t)s->maxDepth + 1;
-	const size_t nl = s->nLights;
-	if (n * (nl + 1) >= 0xffffffffull) return fail(MIRT_E_INVALID, "too many rays per depth for one launch (%zu slots x %zu lights)", n, nl);
-	if ((e = w.hitO.ensure(2 * n * 16))) return e;
-	if ((e = w.hitD.ensure(2 * n * 16))) return e;
-	if ((e = w.hitN.ensure(2 * n * 16))) return e;
-	if ((e = w.shRes.ensure((nl ? n * nl : 1) * 8))) return e;
-	if ((e = w.litL.ensure(depths * n * 16))) return e;
-	if ((e = w.litS.ensure(depths * n * 16))) return e;
-	if ((e = w.pathDepth.ensure(n))) return e;
-	if ((e = w.active.ensure(2 * n * 4))) return e;
-	if ((e = w.counters.ensure(CTR_COUNT * 4))) return e;
-	// the overflow part of the traversal stack is per stream, like everything else a launch writes: launches of frames
-	// on different streams run at the same time with identical grids
-	if (s->deepBvh && (e = w.ovf.ensure((size_t)s->ovfLevels * s->ovfStride * 4))) return e;
 	DFrame F;
-	F.ovf = (uint32_t*)w.ovf.p;
+	F.ovf = (uint32_t*)mem[WS_OVF];
 	F.ovfStride = s->ovfStride;
-	F.hitO = (float4*)w.hitO.p; F.hitD = (float4*)w.hitD.p; F.hitN = (float4*)w.hitN.p;
-	F.shRes = (uint2*)w.shRes.p;
-	F.litL = (float4*)w.litL.p; F.litS = (float4*)w.litS.p;
-	F.pathDepth = (uint8_t*)w.pathDepth.p;
-	F.active = (uint32_t*)w.active.p;
-	F.counters = (uint32_t*)w.counters.p;
+	F.hitO = (float4*)mem[WS_HITO]; F.hitD = (float4*)mem[WS_HITD]; F.hitN = (float4*)mem[WS_HITN];
+	F.shRes = (uint2*)mem[WS_SHRES];
+	F.litL = (float4*)mem[WS_LITL]; F.litS = (float4*)mem[WS_LITS];
+	F.pathDepth = (uint8_t*)mem[WS_PATHDEPTH];
+	F.active = (uint32_t*)mem[WS_ACTIVE];
+	F.counters = (uint32_t*)mem[WS_COUNTERS];
 	F.nSlots = (uint32_t)g.nSlots;
 	F.width = p->width; F.height = p->height;
 	F.tileW = tileW; F.tileH = tileH; F.tilesX = g.tilesX; F.nTilesLocal = g.nLocal;
@@ -500,11 +519,10 @@ int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 	F.divTilesX = make_div(g.tilesX);
 	// bytes of tiles that are not rendered must stay untouched in the full-image layout, so only clear when all are
 	F.preCleared = (packed || p->tile_stride == 1) ? 1u : 0u;
-	HIPCHK(hipEventRecord(c->ev0, st));
-	HIPCHK(hipMemsetAsync(w.counters.p, 0, CTR_COUNT * 4, st));
+	HIPCHK(hipMemsetAsync(F.counters, 0, CTR_COUNT * 4, st));
 	if (F.preCleared) {
 		HIPCHK(hipMemsetAsync(d_out, 0, need, st));
-		HIPCHK(hipMemsetAsync(w.pathDepth.p, 0, n, st));
+		HIPCHK(hipMemsetAsync(F.pathDepth, 0, n, st));
 	}
 	switch (effective_mode(s, p->trace_mode)) {
 	case MODE_FAST:
@@ -518,6 +536,37 @@ int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 		break;
 	}
 	HIPCHK(hipGetLastError());
+	return MIRT_OK;
+}
+
+int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t d_out_bytes, hipStream_t st, bool packed) {
+	uint32_t tileW, tileH;
+	TileGeom g;
+	size_t need;
+	int e = frame_checks(s, p, d_out, d_out_bytes, packed, tileW, tileH, g, need);
+	if (e) return e;
+	HIPCHK(hipSetDevice(s->device));
+	FrameCtx* c = ctx_for(s, st, true);
+	if (!c) return MIRT_E_INVALID;
+	c->lastValid = false;
+	if (g.nSlots == 0) { c->lastPrimary = 0; c->lastFeatures = p->feature_bits; return MIRT_OK; }
+	if (s->maxDepth < 0) {
+		// depth 0 already exceeds maxDepth: computePixelColor returns Color() for every pixel (main.cpp:177,199)
+		HIPCHK(hipMemsetAsync(d_out, 0, need, st));
+		c->lastPrimary = g.livePixels; // the camera ray of every pixel is still made (main.cpp:152)
+		c->lastFeatures = p->feature_bits;
+		return MIRT_OK;
+	}
+	Workspace& w = c->ws;
+	const FrameLayout L = frame_layout(s, (size_t)g.nSlots);
+	DevBuf* const bufs[WS_N] = {&w.hitO, &w.hitD, &w.hitN, &w.shRes, &w.litL, &w.litS, &w.pathDepth, &w.active, &w.counters, &w.ovf};
+	void* mem[WS_N];
+	for (int k = 0; k < WS_N; ++k) {
+		if (L.bytes[k] && (e = bufs[k]->ensure(L.bytes[k]))) return e;
+		mem[k] = bufs[k]->p;
+	}
+	HIPCHK(hipEventRecord(c->ev0, st));
+	if ((e = enqueue_frame(s, c, p, g, tileW, tileH, packed, mem, d_out, need, st))) return e;
 	HIPCHK(hipEventRecord(c->ev1, st));
 	c->lastPrimary = g.livePixels;
 	c->lastFeatures = p->feature_bits;
@@ -564,6 +613,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	HIPCHK(hipSetDevice(device));
 	hipDeviceProp_t prop;
 	HIPCHK(hipGetDeviceProperties(&prop, device));
+	if ((e = scratch_init(device))) return e;
 
 	// MIRT_VERBOSE=1: seconds per phase on stderr
 	const bool verbose = getenv("MIRT_VERBOSE") != nullptr;
@@ -1021,6 +1071,38 @@ size_t mirt_tile_buffer_bytes(const mirt_render_params* p) {
 int mirt_render_device(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t d_out_bytes, void* hip_stream) {
 	if (!p) return fail(MIRT_E_INVALID, "render params are NULL");
 	return render_async(s, p, d_out, d_out_bytes, (hipStream_t)hip_stream, packed_layout(p));
+}
+
+int mirt_render_device_noalloc(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t d_out_bytes, void* hip_stream) {
+	if (!p) return fail(MIRT_E_INVALID, "render params are NULL");
+	const bool packed = packed_layout(p);
+	hipStream_t st = (hipStream_t)hip_stream;
+	uint32_t tileW, tileH;
+	TileGeom g;
+	size_t need;
+	int e = frame_checks(s, p, d_out, d_out_bytes, packed, tileW, tileH, g, need);
+	if (e) return e;
+	if (s->device < 0 || s->device >= MIRT_MAX_DEVICES || !g_scratchPtr[s->device]) return fail(MIRT_E_INVALID, "no scratch array on device %d", s->device);
+	HIPCHK(hipSetDevice(s->device));
+	if (g.nSlots == 0) return MIRT_OK;
+	if (s->maxDepth < 0) { // computePixelColor returns Color() for every pixel (main.cpp:177,199)
+		HIPCHK(hipMemsetAsync(d_out, 0, need, st));
+		return MIRT_OK;
+	}
+	// the arrays of a frame, carved out of this device's scratch array one after the other, each 256-byte aligned
+	const FrameLayout L = frame_layout(s, (size_t)g.nSlots);
+	unsigned char* const base = g_scratchPtr[s->device];
+	void* mem[WS_N];
+	size_t at = 0;
+	for (int k = 0; k < WS_N; ++k) {
+		mem[k] = base + at;
+		at += (L.bytes[k] + 255) & ~(size_t)255;
+	}
+	if (at > (size_t)MIRT_NOALLOC_SCRATCH_BYTES)
+		return fail(MIRT_E_INVALID, "mirt_render_device_noalloc: this frame needs %zu bytes of working memory (%llu pixel slots, %u lights, maxdepth %d), the fixed scratch array holds %zu; use mirt_render_device",
+		            at, (unsigned long long)g.nSlots, s->nLights, s->maxDepth, (size_t)MIRT_NOALLOC_SCRATCH_BYTES);
+	// counters, path depths and the output are cleared inside enqueue_frame; every other array is written before it is read
+	return enqueue_frame(s, nullptr, p, g, tileW, tileH, packed, mem, d_out, need, st);
 }
 
 int mirt_scene_query(mirt_scene* s, uint32_t what, uint64_t* v) {

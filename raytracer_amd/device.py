@@ -68,6 +68,9 @@ class DeviceScene:
     def render_device(self, params, d_out_ptr, d_out_bytes, stream_ptr=0):
         _check(self.lib, self.lib.mirt_render_device(self.h, C.byref(params), C.c_void_p(d_out_ptr), d_out_bytes, C.c_void_p(stream_ptr)))
 
+    def render_device_noalloc(self, params, d_out_ptr, d_out_bytes, stream_ptr=0):
+        _check(self.lib, self.lib.mirt_render_device_noalloc(self.h, C.byref(params), C.c_void_p(d_out_ptr), d_out_bytes, C.c_void_p(stream_ptr)))
+
     def release_stream(self, stream_ptr):
         _check(self.lib, self.lib.mirt_release_stream(self.h, C.c_void_p(stream_ptr)))
 

@@ -1,0 +1,59 @@
+"""GPU: mirt_render_device_noalloc (the entry point that allocates nothing: its working memory is a fixed per-GPU array)
+against mirt_render_device, through the C ABI, byte for byte -- two calls in a row, the second with a smaller frame, so
+that whatever the first call left in the shared array is there when the second runs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from raytracer_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+
+class _Hip:
+    def __init__(self):
+        self.rt = C.CDLL("libamdhip64.so")
+        self.rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.rt.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        self.rt.hipFree.argtypes = [C.c_void_p]
+
+    def alloc(self, n):
+        p = C.c_void_p()
+        assert self.rt.hipMalloc(C.byref(p), n) == 0
+        assert self.rt.hipMemset(p, 0xa5, n) == 0
+        return p.value
+
+    def to_host(self, ptr, n):
+        out = np.zeros(n, np.uint8)
+        assert self.rt.hipDeviceSynchronize() == 0
+        assert self.rt.hipMemcpy(out.ctypes.data, ptr, n, 2) == 0  # hipMemcpyDeviceToHost
+        return out
+
+
+@pytest.mark.parametrize("name", ["scene7", "scene6"])
+def test_noalloc_render_equals_render_device_twice_in_a_row(name, flat_scenes, goldens):
+    from raytracer_amd.device import DeviceScene, MirtError
+    hip = _Hip()
+    g = goldens(name)
+    with DeviceScene(flat_scenes(name), 0) as s:
+        for (w, h), tiles in (((640, 400), {}), ((160, 120), {}), ((200, 136), dict(tile_w=32, tile_h=8, first_tile=1, tile_stride=3))):
+            p = _capi.make_params(w, h, **tiles)
+            nbytes = s.tile_buffer_bytes(p)
+            a, b = hip.alloc(nbytes), hip.alloc(nbytes)
+            s.render_device(p, a, nbytes, 0)            # the existing entry point (library-allocated workspace)
+            s.render_device_noalloc(p, b, nbytes, 0)    # the fixed array
+            want, got = hip.to_host(a, nbytes), hip.to_host(b, nbytes)
+            assert want.any()
+            assert np.array_equal(got, want), "%dx%d: %d bytes differ" % (w, h, int((got != want).sum()))
+            if (w, h) == (160, 120):
+                assert np.array_equal(got.reshape(h, w, 3), g["bgr_f15"])  # and both are the reference's image
+            hip.rt.hipFree(a)
+            hip.rt.hipFree(b)
+        # a frame beyond the fixed array is refused with a message, nothing is launched
+        big = _capi.make_params(3840, 2160)
+        buf = hip.alloc(64)
+        with pytest.raises(MirtError, match="scratch array holds"):
+            s.render_device_noalloc(big, buf, 3840 * 2160 * 3, 0)
+        hip.rt.hipFree(buf)
