@@ -266,7 +266,7 @@ def main():
             prim_flops = (TRI_FLOPS if flat.tri_verts.shape[0] >= flat.spheres.shape[0] else SPHERE_FLOPS)
             frame_flops = sum(float(rays[k]) * (float(vis[k][0]) * NODE_FLOPS + float(vis[k][2]) * prim_flops) / max(int(srays[k]), 1) for k in range(3))
             # dominant kernels: everything that walks the tree (primary + trace + shade); resolve is the remainder
-            walk_ms = sum(kern[k]["ms_per_frame"] for k in ("primary", "trace", "shade") if k in kern)
+            walk_ms = sum(kern[k]["ms_per_frame"] for k in ("primary", "trace", "shade", "frame") if k in kern)
             achieved = frame_bytes / (walk_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "r01", "hbm_traffic.json")
@@ -274,7 +274,7 @@ def main():
                 traffic = json.load(open(tpath))["hbm_bytes_per_frame"]
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "k_trace (+ k_shade): the launches of one frame that walk the scene, %d launches; durations = HIP events in the timed region" % sum(kern[k]["launches_per_frame"] for k in ("primary", "trace", "shade") if k in kern),
+                "kernel": "k_trace (+ k_shade): the launches of one frame that walk the scene, %d launches; durations = HIP events in the timed region" % sum(kern[k]["launches_per_frame"] for k in ("primary", "trace", "shade", "frame") if k in kern),
                 "algorithmic_bytes_per_ray": {"primary": per_ray[0], "shadow": per_ray[1], "reflection": per_ray[2]},
                 "algorithmic_bytes_per_frame": frame_bytes,
                 "traffic_note": "HBM bytes of one frame from rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/r01/hbm_traffic.json",
@@ -285,7 +285,7 @@ def main():
                               "frac": frame_flops / (walk_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "algorithmic_flops_per_frame": frame_flops,
                               "achieved_per_step": frame_flops / (elapsed / args.steps) / 1e12},
                 "achieved_per_step_GBs": frame_bytes / (elapsed / args.steps) / 1e9,
-                "achieved_frame_alone_GBs": frame_bytes / (sum(kern_alone[k]["ms_per_frame"] for k in ("primary", "trace", "shade") if k in kern_alone) * 1e-3) / 1e9,
+                "achieved_frame_alone_GBs": frame_bytes / (sum(kern_alone[k]["ms_per_frame"] for k in ("primary", "trace", "shade", "frame") if k in kern_alone) * 1e-3) / 1e9,
             }
         print(json.dumps(out), flush=True)
     scene.close()

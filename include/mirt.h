@@ -222,6 +222,7 @@ int mirt_scene_query(mirt_scene* scene, uint32_t what, uint64_t* value_out);
 #define MIRT_K_TRACE 1
 #define MIRT_K_SHADE 2
 #define MIRT_K_RESOLVE 3
+#define MIRT_K_FRAME 4 /* the whole frame in one launch (the usual case; then it is the only entry) */
 int mirt_set_profiling(mirt_scene* scene, int enabled);
 int mirt_get_launch_times(mirt_scene* scene, void* hip_stream, float* ms_out, int32_t* kinds_out, uint32_t capacity, uint32_t* n_out);
 

@@ -16,8 +16,8 @@ F_DIFFUSE, F_SPECULAR, F_SHADOWS, F_REFLECTIONS, F_ALL = 1, 2, 4, 8, 15
 (DEBUG_DIFFUSE_INTENSITY, DEBUG_SPECULAR_INTENSITY, DEBUG_NORMAL_MAP, DEBUG_SHADOW_MAP,
  DEBUG_PRIMARY_MAP, DEBUG_LIGHT_DIRECTION_MAP, DEBUG_NONE) = range(7)
 TRACE_EXACT, TRACE_FAST, TRACE_REFWALK = 0, 1, 2
-K_PRIMARY, K_TRACE, K_SHADE, K_RESOLVE = range(4)
-KERNEL_NAMES = ["primary", "trace", "shade", "resolve"]
+K_PRIMARY, K_TRACE, K_SHADE, K_RESOLVE, K_FRAME = range(5)
+KERNEL_NAMES = ["primary", "trace", "shade", "resolve", "frame"]
 
 
 class Node(C.Structure):

@@ -150,6 +150,7 @@ struct FrameCtx {
 	uint64_t lastPrimary = 0;
 	uint32_t lastFeatures = 0;
 	bool lastValid = false;
+	bool lastSingle = false; // the last frame ran as one launch (k_frame): its counters are laid out differently
 	std::vector<hipEvent_t> launchEv;
 	std::vector<int32_t> launchKind;
 	uint32_t nLaunches = 0;
@@ -183,6 +184,7 @@ struct mirt_scene {
 	uint32_t diag[8] = {0}; // builder facts: binary interior nodes, binary leaves, wide nodes with 1..4 children
 	std::vector<FrameCtx*> ctxs; // one per stream that has rendered with this scene
 	bool profiling = false;
+	bool singleLaunch = true; // frames run as one launch (k_frame) where that kernel applies; MIRT_SINGLE_LAUNCH=0: one launch per depth
 };
 
 namespace {
@@ -465,18 +467,30 @@ enum { WS_HITO, WS_HITD, WS_HITN, WS_SHRES, WS_LITL, WS_LITS, WS_PATHDEPTH, WS_A
 struct FrameLayout {
 	size_t bytes[WS_N];
 };
-FrameLayout frame_layout(const mirt_scene* s, size_t n) {
+// Does this frame run as ONE launch (k_frame)?  Not the walk of the reference's own tree (fallback mode, one wave per
+// SIMD), not scenes big enough for lane refilling to pay (k_trace<REFILL> has no counterpart there), not frames whose slot
+// numbers do not fit beside the depth in one word.
+bool single_launch(const mirt_scene* s, const mirt_render_params* p, const TileGeom& g) {
+	return s->singleLaunch && effective_mode(s, p->trace_mode) != MODE_REFWALK && s->refillMin >= 64u && g.nSlots < (1ull << FRAME_SLOT_BITS) && s->maxDepth <= 31;
+}
+
+FrameLayout frame_layout(const mirt_scene* s, size_t n, bool single) {
 	const size_t depths = (size_t)s->maxDepth + 1, nl = s->nLights;
 	FrameLayout L;
+	memset(&L, 0, sizeof L);
+	L.bytes[WS_COUNTERS] = CTR_COUNT * 4;
+	L.bytes[WS_OVF] = s->deepBvh ? (size_t)s->ovfLevels * s->ovfStride * 4 : 0;
+	if (single) {
+		// k_frame: one hit record per slot, one light sum (with the material index) per slot and depth
+		L.bytes[WS_HITO] = L.bytes[WS_HITD] = L.bytes[WS_HITN] = n * 16;
+		L.bytes[WS_LITL] = depths * n * 16;
+		return L;
+	}
 	L.bytes[WS_HITO] = L.bytes[WS_HITD] = L.bytes[WS_HITN] = 2 * n * 16;
 	L.bytes[WS_SHRES] = (nl ? n * nl : 1) * 8;
 	L.bytes[WS_LITL] = L.bytes[WS_LITS] = depths * n * 16;
 	L.bytes[WS_PATHDEPTH] = n;
 	L.bytes[WS_ACTIVE] = 2 * n * 4;
-	L.bytes[WS_COUNTERS] = CTR_COUNT * 4;
-	// the overflow part of the traversal stack belongs to the frame like everything else a launch writes: launches of
-	// frames on different streams run at the same time with identical grids
-	L.bytes[WS_OVF] = s->deepBvh ? (size_t)s->ovfLevels * s->ovfStride * 4 : 0;
 	return L;
 }
 
@@ -495,7 +509,7 @@ int frame_checks(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 
 // Puts one frame on the stream: clears, every launch of the frame.  mem[] are the arrays of frame_layout(); c may be NULL
 // (no per-launch profiling then).  Allocates nothing.
-int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const TileGeom& g, uint32_t tileW, uint32_t tileH, bool packed,
+int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const TileGeom& g, uint32_t tileW, uint32_t tileH, bool packed, bool single,
                   void* const mem[WS_N], void* d_out, size_t need, hipStream_t st) {
 	const size_t n = (size_t)g.nSlots;
 	DFrame F;
@@ -522,7 +536,23 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 	HIPCHK(hipMemsetAsync(F.counters, 0, CTR_COUNT * 4, st));
 	if (F.preCleared) {
 		HIPCHK(hipMemsetAsync(d_out, 0, need, st));
-		HIPCHK(hipMemsetAsync(F.pathDepth, 0, n, st));
+		if (!single) HIPCHK(hipMemsetAsync(F.pathDepth, 0, n, st));
+	}
+	if (single) {
+		const int grid = s->numCUs * GRID_BLOCKS_PER_CU;
+		if (c) c->nLaunches = 0;
+		mark(s, c, st, -1);
+		if (effective_mode(s, p->trace_mode) == MODE_FAST) {
+			if (s->deepBvh) hipLaunchKernelGGL((k_frame<MODE_FAST, true>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, (uint8_t*)d_out);
+			else hipLaunchKernelGGL((k_frame<MODE_FAST, false>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, (uint8_t*)d_out);
+		}
+		else {
+			if (s->deepBvh) hipLaunchKernelGGL((k_frame<MODE_EXACT, true>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, (uint8_t*)d_out);
+			else hipLaunchKernelGGL((k_frame<MODE_EXACT, false>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, (uint8_t*)d_out);
+		}
+		mark(s, c, st, MIRT_K_FRAME);
+		HIPCHK(hipGetLastError());
+		return MIRT_OK;
 	}
 	switch (effective_mode(s, p->trace_mode)) {
 	case MODE_FAST:
@@ -558,7 +588,8 @@ int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 		return MIRT_OK;
 	}
 	Workspace& w = c->ws;
-	const FrameLayout L = frame_layout(s, (size_t)g.nSlots);
+	const bool single = single_launch(s, p, g);
+	const FrameLayout L = frame_layout(s, (size_t)g.nSlots, single);
 	DevBuf* const bufs[WS_N] = {&w.hitO, &w.hitD, &w.hitN, &w.shRes, &w.litL, &w.litS, &w.pathDepth, &w.active, &w.counters, &w.ovf};
 	void* mem[WS_N];
 	for (int k = 0; k < WS_N; ++k) {
@@ -566,8 +597,9 @@ int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 		mem[k] = bufs[k]->p;
 	}
 	HIPCHK(hipEventRecord(c->ev0, st));
-	if ((e = enqueue_frame(s, c, p, g, tileW, tileH, packed, mem, d_out, need, st))) return e;
+	if ((e = enqueue_frame(s, c, p, g, tileW, tileH, packed, single, mem, d_out, need, st))) return e;
 	HIPCHK(hipEventRecord(c->ev1, st));
+	c->lastSingle = single;
 	c->lastPrimary = g.livePixels;
 	c->lastFeatures = p->feature_bits;
 	c->lastValid = true;
@@ -584,6 +616,19 @@ int read_stats(mirt_scene* s, hipStream_t st, mirt_stats* out) {
 	uint32_t cnt[CTR_COUNT];
 	HIPCHK(hipMemcpy(cnt, c->ws.counters.p, sizeof cnt, hipMemcpyDeviceToHost));
 	uint64_t hits = 0, refl = 0;
+	if (c->lastSingle) {
+		hits = cnt[CTR_F_HITS_TOTAL];
+		// a reflection ray for every hit that is not at the last depth (main.cpp:177,189-190)
+		refl = (c->lastFeatures & MIRT_F_REFLECTIONS) ? hits - cnt[CTR_F_HITS_LAST] : 0;
+		out->primary_hits = cnt[CTR_F_HITS_PRIMARY];
+		out->shadow_rays = hits * s->nLights;
+		out->shadow_rays_traced = cnt[CTR_F_SHADOW_TRACED];
+		out->reflection_rays = out->reflection_rays_traced = refl;
+		float ms1 = 0.0f;
+		HIPCHK(hipEventElapsedTime(&ms1, c->ev0, c->ev1));
+		out->device_ms = ms1;
+		return MIRT_OK;
+	}
 	for (int d = 0; d <= s->maxDepth; ++d) hits += cnt[CTR_NHITS(d)];
 	// a reflection ray is traced for every hit at depth d < maxDepth when REFLECTIONS is on (main.cpp:177,189-190)
 	if (c->lastFeatures & MIRT_F_REFLECTIONS) for (int d = 0; d < s->maxDepth; ++d) refl += cnt[CTR_NHITS(d)];
@@ -877,6 +922,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	s->bvhDepth = bvhWideDepth;
 	// Long walks (big scenes) make refilling idle lanes pay; short ones do not (see k_trace).  MIRT_REFILL_MIN overrides.
 	s->refillMin = bvhWide.size() / 16 > 500000u ? 36u : 64u;
+	if (const char* env = getenv("MIRT_SINGLE_LAUNCH")) s->singleLaunch = atoi(env) != 0;
 	if (const char* env = getenv("MIRT_REFILL_MIN")) { const int v = atoi(env); if (v >= 1 && v <= 64) s->refillMin = (uint32_t)v; }
 	memcpy(s->diag, bvhDiag, sizeof bvhDiag);
 	ds.bvhRoot = bvhRoot;
@@ -1090,7 +1136,8 @@ int mirt_render_device_noalloc(mirt_scene* s, const mirt_render_params* p, void*
 		return MIRT_OK;
 	}
 	// the arrays of a frame, carved out of this device's scratch array one after the other, each 256-byte aligned
-	const FrameLayout L = frame_layout(s, (size_t)g.nSlots);
+	const bool single = single_launch(s, p, g);
+	const FrameLayout L = frame_layout(s, (size_t)g.nSlots, single);
 	unsigned char* const base = g_scratchPtr[s->device];
 	void* mem[WS_N];
 	size_t at = 0;
@@ -1102,7 +1149,7 @@ int mirt_render_device_noalloc(mirt_scene* s, const mirt_render_params* p, void*
 		return fail(MIRT_E_INVALID, "mirt_render_device_noalloc: this frame needs %zu bytes of working memory (%llu pixel slots, %u lights, maxdepth %d), the fixed scratch array holds %zu; use mirt_render_device",
 		            at, (unsigned long long)g.nSlots, s->nLights, s->maxDepth, (size_t)MIRT_NOALLOC_SCRATCH_BYTES);
 	// counters, path depths and the output are cleared inside enqueue_frame; every other array is written before it is read
-	return enqueue_frame(s, nullptr, p, g, tileW, tileH, packed, mem, d_out, need, st);
+	return enqueue_frame(s, nullptr, p, g, tileW, tileH, packed, single, mem, d_out, need, st);
 }
 
 int mirt_scene_query(mirt_scene* s, uint32_t what, uint64_t* v) {

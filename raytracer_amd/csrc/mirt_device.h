@@ -122,4 +122,11 @@ struct DFrame {
 #define CTR_CURSOR(launch) (launch)              // 0..63  one dynamic-chunk cursor per kernel launch of the frame
 #define CTR_NHITS(depth) (64 + (depth))          // hits found at this depth
 #define CTR_NSHADOW(depth) (64 + 64 + (depth))   // shadow queries traced for the hits of this depth
-#define CTR_COUNT 192
+// k_frame (one launch per frame) uses the same block differently:
+#define CTR_F_PCUR 0            // next block of pixel slots to hand out
+#define CTR_F_HITS_PRIMARY 64   // == CTR_NHITS(0): primary rays that hit
+#define CTR_F_HITS_TOTAL 65     // hits at all depths
+#define CTR_F_HITS_LAST 66      // hits at the last depth (they spawn no reflection ray)
+#define CTR_F_SHADOW_TRACED 128 // == CTR_NSHADOW(0): shadow queries that were walked
+#define CTR_COUNT 256
+#define FRAME_SLOT_BITS 27    // k_frame packs slot and depth into one word: fewer than 2^27 slots, depth <= 31

@@ -68,14 +68,9 @@ __device__ __forceinline__ float inv_sqrt(float x) { return 1.0f / sqrtf(x); }
 __device__ __forceinline__ f3 normalize3(f3 a) { return a * inv_sqrt(dot3(a, a)); }
 __device__ __forceinline__ float length3(f3 a) { return sqrtf(dot3(a, a)); }
 
-// glm::pow(float, float) = powf of the C library the reference is linked against (main.cpp:263): glibc's powf, restated
-// bit for bit in mirt_powf.h for positive finite bases; zeros, NaNs, infinities and overflow have exact IEEE answers, which
-// the generic double-precision pow gives after one rounding to float.
-__device__ __forceinline__ float ref_powf(float x, float y) {
-	float r;
-	if (mirt_powf::powf_glibc(x, y, r)) return r;
-	return (float)pow((double)x, (double)y);
-}
+// glm::pow(float, float) = powf of the C library the reference is linked against (main.cpp:263): glibc's powf, which is
+// not correctly rounded; restated bit for bit in mirt_powf.h.
+__device__ __forceinline__ float ref_powf(float x, float y) { return mirt_powf::powf_glibc(x, y); }
 
 struct Hit {
 	float dist;   // world distance |P - o| (Intersection::distAlongRay); +inf = miss
@@ -1005,6 +1000,52 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MODE == M
 	if (lane == 0 && nShadowTraced) atomicAdd(F.counters + CTR_NSHADOW(depth - 1), nShadowTraced);
 }
 
+// One light's turn of the loop in calculateLightingColor (main.cpp:208-253): adds the light's term to `sum`.
+// o = origin of the ray that hit, P = the hit point, N = the hit's normal, mat = the hit primitive's material record;
+// occRef/occDist = answer of the light's shadow query (REF_NONE: nothing in the way).
+__device__ __forceinline__ void shade_light(const DScene& S, uint32_t features, uint32_t debug, f3 o, f3 P, f3 N, const float4* __restrict__ mat, uint32_t li,
+                                            bool shadows, uint32_t occRef, float occDist, f3& sum) {
+	const float4 ll = S.lights[li * 2], lc = S.lights[li * 2 + 1];
+	f3 L;
+	float atten;
+	if (ll.w > 0.0f) {                                              // :213
+		L = F3(ll) - P;                                             // :214
+		const float dl = length3(L);                                // :215
+		// :266-268; glm::pow(distance, 2.0f) is dl * dl in the reference's build: g++ folds a power with the
+		// constant exponent 2 into a multiplication (one mulss in the machine code of calculateAttenuation)
+		atten = 1.0f / (S.atten[0] + S.atten[1] * dl + S.atten[2] * (dl * dl));
+	}
+	else {
+		L = F3(ll);                                                 // :219
+		atten = 1.0f;
+	}
+	const f3 Ln = normalize3(L);                                    // :222
+	// shadow query: any hit closer than |L| was reported; SHADOW_MAP view: nearest hit, compared here (main.cpp:224)
+	const bool lit = !shadows || (occRef == REF_NONE) || (debug == D_SHADOW_MAP && occDist >= length3(L));
+	if (lit) {
+		// std::max(x, 0.0f) is (x < 0.0f) ? 0.0f : x: a NaN (zero-length L or N) stays a NaN, fmaxf would drop it
+		const float kdRaw = dot3(normalize3(N), normalize3(L));
+		const float kd = (kdRaw < 0.0f) ? 0.0f : kdRaw;                      // :225, :258-260
+		const f3 eye = o - P;                                                // :226
+		const f3 H = normalize3(Ln + normalize3(eye));                       // :227
+		const float ksRaw = dot3(H, N);
+		const float4 mDiff = mat[0], mSpec = mat[1];
+		const float ks = ref_powf((ksRaw < 0.0f) ? 0.0f : ksRaw, mDiff.w);   // :262-264, shininess
+		if (debug == D_DIFFUSE_INTENSITY) sum = sum + F3(kd, kd, kd);
+		else if (debug == D_SPECULAR_INTENSITY) sum = sum + F3(ks, ks, ks);
+		else if (debug == D_NORMAL_MAP) sum = sum + N;
+		else if (debug == D_LIGHT_DIR_MAP) sum = sum + H;
+		else {
+			if (features & F_DIFFUSE) sum = sum + ((F3(mDiff) * atten) * kd) * F3(lc);  // :243
+			if (features & F_SPECULAR) sum = sum + ((F3(mSpec) * atten) * ks) * F3(lc); // :246
+		}
+	}
+	else if (debug == D_SHADOW_MAP) {
+		const float4* om = S.materials + (size_t)info_of(S, occRef).y * 4;
+		sum = sum + F3(om[0]);                                      // :250-252
+	}
+}
+
 // ---- once the shadow queries are answered: calculateLightingColor (main.cpp:203-256) for every hit of one depth ----------------
 __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, DFrame F, int depth) {
 	const size_t rd = (size_t)(depth & 1) * F.nSlots;
@@ -1017,55 +1058,18 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene S, DFrame F, int depth) 
 		const f3 o = F3(ho), d = F3(hd), N = F3(hn);
 		const uint32_t ref = __float_as_uint(hn.w);
 		const float4* mat = S.materials + (size_t)info_of(S, ref).y * 4;
-		const float4 mDiff = mat[0], mSpec = mat[1], mEmis = mat[2], mAmb = mat[3];
-		const float shininess = mDiff.w;
+		const float4 mSpec = mat[1], mEmis = mat[2], mAmb = mat[3];
 		const f3 P = o + normalize3(d) * hd.w;                               // Camera.cpp:26-28
 		f3 sum = F3(mAmb) + F3(mEmis);                                      // main.cpp:204
 		for (uint32_t li = 0; li < S.nLights; ++li) {                       // :208
-			const float4 ll = S.lights[li * 2], lc = S.lights[li * 2 + 1];
-			f3 L;
-			float atten;
-			if (ll.w > 0.0f) {                                              // :213
-				L = F3(ll) - P;                                             // :214
-				const float dl = length3(L);                                // :215
-				// :266-268; glm::pow(distance, 2.0f) is dl * dl in the reference's build: g++ folds a power with the
-				// constant exponent 2 into a multiplication (one mulss in the machine code of calculateAttenuation)
-				atten = 1.0f / (S.atten[0] + S.atten[1] * dl + S.atten[2] * (dl * dl));
-			}
-			else {
-				L = F3(ll);                                                 // :219
-				atten = 1.0f;
-			}
-			const f3 Ln = normalize3(L);                                    // :222
-			bool lit = true;
 			uint32_t occRef = REF_NONE;
+			float occDist = __builtin_inff();
 			if (shadows) {
 				const uint2 res = F.shRes[(size_t)slot * S.nLights + li];
 				occRef = res.x;
-				// shadow query: any hit closer than |L| was reported; SHADOW_MAP view: nearest hit, compared here (main.cpp:224)
-				lit = (occRef == REF_NONE) || (F.debug == D_SHADOW_MAP && __uint_as_float(res.y) >= length3(L));
+				occDist = __uint_as_float(res.y);
 			}
-			if (lit) {
-				// std::max(x, 0.0f) is (x < 0.0f) ? 0.0f : x: a NaN (zero-length L or N) stays a NaN, fmaxf would drop it
-				const float kdRaw = dot3(normalize3(N), normalize3(L));
-				const float kd = (kdRaw < 0.0f) ? 0.0f : kdRaw;                      // :225, :258-260
-				const f3 eye = o - P;                                                // :226
-				const f3 H = normalize3(Ln + normalize3(eye));                       // :227
-				const float ksRaw = dot3(H, N);
-				const float ks = ref_powf((ksRaw < 0.0f) ? 0.0f : ksRaw, shininess);   // :262-264
-				if (F.debug == D_DIFFUSE_INTENSITY) sum = sum + F3(kd, kd, kd);
-				else if (F.debug == D_SPECULAR_INTENSITY) sum = sum + F3(ks, ks, ks);
-				else if (F.debug == D_NORMAL_MAP) sum = sum + N;
-				else if (F.debug == D_LIGHT_DIR_MAP) sum = sum + H;
-				else {
-					if (F.features & F_DIFFUSE) sum = sum + ((F3(mDiff) * atten) * kd) * F3(lc);  // :243
-					if (F.features & F_SPECULAR) sum = sum + ((F3(mSpec) * atten) * ks) * F3(lc); // :246
-				}
-			}
-			else if (F.debug == D_SHADOW_MAP) {
-				const float4* om = S.materials + (size_t)info_of(S, occRef).y * 4;
-				sum = sum + F3(om[0]);                                      // :250-252
-			}
+			shade_light(S, F.features, F.debug, o, P, N, mat, li, shadows, occRef, occDist, sum);
 		}
 		const size_t k = (size_t)depth * F.nSlots + slot;
 		F.litL[k] = make_float4(sum.x, sum.y, sum.z, 0.0f);
@@ -1101,6 +1105,250 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DFrame F, uint8_t* __restrict
 		out[o] = quantise(C.z);     // B  main.cpp:154
 		out[o + 1] = quantise(C.y); // G
 		out[o + 2] = quantise(C.x); // R
+	}
+}
+
+// ---- the whole frame in ONE launch --------------------------------------------------------------------------------------
+// k_trace / k_shade / k_resolve above run a frame as one launch per depth: depth d+1 starts when depth d has ended, and
+// the deep bounces -- a few thousand rays each -- leave the GPU nearly empty for most of a frame's duration.  k_frame is
+// the same arithmetic as a data flow: a path's next ray starts as soon as the hit it leaves from exists.
+//
+// Work never fans out: a pixel slot yields at most one hit, and a hit at most one further hit (main.cpp:176-201 recurses
+// once), so a wave keeps what it produces and no wave ever waits for another.  A wave
+//   * takes pixel slots (its own first block, then blocks from the launch's cursor), 64 to a batch, walks their camera
+//     rays, and puts the slots that hit into its list in LDS (entry = slot | depth << 27);
+//   * whenever the list holds 64 entries it works on those before taking new slots (at the end, on what is left).
+//     Working on a hit is calculateLightingColor and the reflection of computePixelColor (main.cpp:187-190) in one go,
+//     all lanes in step: for every light in file order one batch of shadow queries, each lane adding the light's term to
+//     its own sum right after the walk (shade_light: the operations and the order of k_shade); then one batch of
+//     reflection rays, whose hits go back into the list with depth + 1; a path that ends (reflections off, a miss, or
+//     the last depth) is folded back to front over its stored light sums, C = L_k + S_k C (k_resolve's loop), and its
+//     pixel is written.
+// Per-path data: one hit record per slot (the record of depth d is dead once its lane has written the record of depth
+// d+1 over it) and one light sum per slot and depth; both are written and read by the same wave only.
+#define FRAME_SLOT_MASK ((1u << FRAME_SLOT_BITS) - 1u)
+
+template <int MODE, bool OVF>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_BATCH_WAVES))) void k_frame(DScene S, DFrame F, uint8_t* __restrict__ out) {
+	__shared__ uint32_t s_stack[STACK_LDS * BLOCK];
+	__shared__ uint32_t s_list[BLOCK / WAVE][128];
+	LdsStack<OVF, STACK_LDS> stk;
+	stk.lds = s_stack + threadIdx.x;
+	stk.ovf = OVF ? F.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
+	stk.ovfStride = F.ovfStride;
+	const int lane = threadIdx.x & 63;
+	const unsigned long long ltMask = (1ull << lane) - 1ull;
+	uint32_t* myList = s_list[threadIdx.x >> 6];
+	uint32_t nbuf = 0;            // entries in the list: fewer than 64 before a batch, fewer than 128 after
+	const bool reflections = (F.features & F_REFLECTIONS) != 0;
+	const bool shadows = (F.features & F_SHADOWS) != 0;
+	const uint32_t last = reflections ? (uint32_t)S.maxDepth : 0u; // deepest hit a path can have (main.cpp:177)
+	// pixel slots come in blocks: a wave's first block is its own, later ones come from the cursor (one atomic per block; a
+	// single address sustains only ~88 atomics per microsecond).  Blocks shrink towards the end of the slots, so that the
+	// last paths to start are spread over many waves.
+	const uint32_t nWaves = gridDim.x * (BLOCK / WAVE);
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
+	const uint32_t per0 = F.nSlots / (2u * nWaves);
+	const uint32_t blk0 = per0 >= 256u ? 256u : (per0 >= 128u ? 128u : 64u);
+	uint32_t pb = wave * blk0, pe = pb + blk0, blk = blk0;
+	uint32_t nShadowTraced = 0;   // per lane
+	uint32_t nHit0 = 0, nHitAll = 0, nHitLast = 0; // per wave
+	Walker<MODE, OVF> w;
+	// The wave works in rounds; every round is: set up to 64 rays, walk them (ONE copy of the walk in the kernel), use the
+	// answers.  ROUND_PRIMARY: 64 camera rays.  A batch of hits takes ROUND_LIGHT once per light, then ROUND_REFLECT.
+	enum { ROUND_PRIMARY, ROUND_LIGHT, ROUND_REFLECT };
+	int round = ROUND_PRIMARY;
+	uint32_t li = 0;              // the light of ROUND_LIGHT
+	uint32_t entry = 0xffffffffu; // this lane's hit of the current batch (slot | depth << 27), or none
+	uint32_t tag = 0;             // ROUND_PRIMARY: this lane's slot
+	f3 sum = F3(0, 0, 0);         // the hit's light sum so far (main.cpp:204-253)
+	uint32_t matIndex = 0;
+	bool inBatch = false;         // a batch of hits is being worked on
+	for (;;) {
+		// ---- which round, and its rays --------------------------------------------------------------------------------
+		bool walk = false;        // this lane has a ray in this round
+		w.cur = BVH_DONE;
+		w.best.ref = REF_NONE;
+		w.best.dist = __builtin_inff();
+		if (!inBatch) {
+			if (nbuf < 64u && pb >= pe && pb < F.nSlots) {
+				uint32_t c = 0;
+				if (lane == 0) c = atomicAdd(F.counters + CTR_F_PCUR, blk);
+				pb = __builtin_amdgcn_readfirstlane(c) + nWaves * blk0;
+				pe = pb + blk;
+				const uint32_t rest = pe < F.nSlots ? F.nSlots - pe : 0u, per = rest / (2u * nWaves);
+				blk = per >= 256u ? 256u : (per >= 128u ? 128u : 64u);
+				if (blk > blk0) blk = blk0;
+			}
+			if (nbuf < 64u && pb < pe && pb < F.nSlots) {
+				// up to 64 camera rays (main.cpp:152-153, depth 0)
+				round = ROUND_PRIMARY;
+				const uint32_t end = pe < F.nSlots ? pe : F.nSlots;
+				const uint32_t got = end - pb < 64u ? end - pb : 64u;
+				tag = pb + (uint32_t)lane;
+				pb += got;
+				if ((uint32_t)lane < got) {
+					uint32_t px, py, inTile;
+					if (slot_to_pixel(F, tag, px, py, inTile)) { // false: padding pixel of an edge tile
+						f3 o, d;
+						primary_ray(S, px, py, F.width, F.height, o, d);
+						w.start(S, o, d, -1.0f);
+						walk = true;
+					}
+				}
+			}
+			else {
+				if (nbuf == 0u) break; // no slots left and no hits left: this wave is done
+				// up to 64 hits: their lights, then their reflection rays (main.cpp:187-190)
+				const uint32_t take = nbuf < 64u ? nbuf : 64u;
+				nbuf -= take;
+				entry = (uint32_t)lane < take ? myList[nbuf + (uint32_t)lane] : 0xffffffffu;
+				if (entry != 0xffffffffu) {
+					matIndex = info_of(S, __float_as_uint(F.hitN[entry & FRAME_SLOT_MASK].w)).y;
+					const float4* mat = S.materials + (size_t)matIndex * 4;
+					sum = F3(mat[3]) + F3(mat[2]);                           // main.cpp:204: ambient + emission
+				}
+				inBatch = true;
+				li = 0;
+				round = S.nLights ? ROUND_LIGHT : ROUND_REFLECT;
+			}
+		}
+		const bool has = inBatch && entry != 0xffffffffu;
+		const uint32_t slot = entry & FRAME_SLOT_MASK, depth = has ? entry >> FRAME_SLOT_BITS : 0u;
+		if (inBatch && round == ROUND_LIGHT) {
+			if (has && shadows) {                                            // main.cpp:208-224
+				const float4 ho = F.hitO[slot], hd = F.hitD[slot];
+				const f3 po = F3(ho), pd = F3(hd);
+				const f3 P = po + normalize3(pd) * hd.w;                     // Camera.cpp:26-28
+				const float4 ll = S.lights[li * 2];
+				const f3 L = ll.w > 0.0f ? F3(ll) - P : F3(ll);              // main.cpp:213-219
+				const f3 dir = normalize3(L);                                // :222
+				const float dl = length3(L);
+				walk = true;
+				// a query whose light term is multiplied by exact zeros is answered without a walk (see item_ray)
+				if (S.shadowCull && F.debug == D_NONE) {
+					const f3 N = F3(F.hitN[slot]);
+					const bool kd0 = !(F.features & F_DIFFUSE) || dot3(normalize3(N), normalize3(L)) <= 0.0f;
+					bool ks0 = !(F.features & F_SPECULAR);
+					if (!ks0) {
+						const f3 H = normalize3(dir + normalize3(po - P));
+						ks0 = dot3(H, N) <= 0.0f;
+					}
+					const float atten = ll.w > 0.0f ? 1.0f / (S.atten[0] + S.atten[1] * dl + S.atten[2] * (dl * dl)) : 1.0f;
+					if (kd0 && ks0 && fabsf(atten) <= 1e15f) walk = false;
+				}
+				if (walk) {
+					++nShadowTraced;
+					w.start(S, P, dir, F.debug == D_SHADOW_MAP ? -2.0f : dl); // :223-224 (SHADOW_MAP wants the nearest occluder)
+				}
+			}
+		}
+		else if (inBatch) { // ROUND_REFLECT: a path goes on while depth + 1 <= maxDepth (main.cpp:177,189-190)
+			if (has && depth < last) {
+				const float4 ho = F.hitO[slot], hd = F.hitD[slot], hn = F.hitN[slot];
+				const f3 pd = F3(hd), N = F3(hn);
+				const f3 P = F3(ho) + normalize3(pd) * hd.w;
+				w.start(S, P, normalize3(pd - N * (2.0f * dot3(pd, N))), -1.0f);  // main.cpp:188
+				walk = true;
+			}
+		}
+		// ---- the walk ------------------------------------------------------------------------------------------------
+		const unsigned long long walked = __builtin_amdgcn_ballot_w64(walk);
+		if (walked) {
+			walk_wave<false, false>(S, w, stk);
+			// deferred check of the final answers; the rare ray that fails it is walked again, strictly
+			if (MODE == MODE_EXACT) {
+				const bool redo = walk && !w.verify(S);
+				if (__builtin_amdgcn_ballot_w64(redo)) {
+					if (redo) w.start(S, w.r.o, w.r.d, w.limit);
+					walk_wave<false, true>(S, w, stk);
+				}
+			}
+		}
+		const bool hit = walk && w.best.ref != REF_NONE;
+		// ---- what the answers mean -------------------------------------------------------------------------------------
+		if (!inBatch) {
+			const bool red = hit && F.debug == D_PRIMARY_MAP;   // PRIMARY_INTERSECTION_MAP paints hits pure red (main.cpp:183-185)
+			if (red || (walk && !hit && !F.preCleared)) {       // the background is black (main.cpp:124,180)
+				uint32_t px, py, inTile;
+				slot_to_pixel(F, tag, px, py, inTile);
+				const size_t k = out_offset(F, tag, px, py, inTile);
+				out[k] = 0;
+				out[k + 1] = 0;
+				out[k + 2] = hit ? 255 : 0;
+			}
+			const bool newHit = hit && !red;
+			if (newHit) {
+				const f3 n = hit_normal(S, w.r, w.best.ref);
+				F.hitO[tag] = make_float4(w.r.o.x, w.r.o.y, w.r.o.z, 0.0f);
+				F.hitD[tag] = make_float4(w.r.d.x, w.r.d.y, w.r.d.z, w.best.dist);
+				F.hitN[tag] = make_float4(n.x, n.y, n.z, __uint_as_float(w.best.ref));
+			}
+			const uint32_t nh = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(hit));
+			nHit0 += nh;
+			nHitAll += nh;
+			if (last == 0u) nHitLast += nh;
+			const unsigned long long hm = __builtin_amdgcn_ballot_w64(newHit);
+			if (hm) {
+				if (newHit) myList[nbuf + (uint32_t)__popcll(hm & ltMask)] = tag; // depth 0
+				nbuf += (uint32_t)__popcll(hm);
+			}
+			continue;
+		}
+		if (round == ROUND_LIGHT) {
+			if (has) {
+				const float4 ho = F.hitO[slot], hd = F.hitD[slot], hn = F.hitN[slot];
+				const f3 po = F3(ho);
+				const f3 P = po + normalize3(F3(hd)) * hd.w;
+				shade_light(S, F.features, F.debug, po, P, F3(hn), S.materials + (size_t)matIndex * 4, li, shadows,
+				            hit ? w.best.ref : REF_NONE, hit ? w.best.dist : __builtin_inff(), sum);
+			}
+			if (++li >= S.nLights) round = ROUND_REFLECT;
+			continue;
+		}
+		// ROUND_REFLECT: the hit's light sum is complete
+		if (has) F.litL[(size_t)depth * F.nSlots + slot] = make_float4(sum.x, sum.y, sum.z, __uint_as_float(matIndex));
+		if (hit) {
+			const f3 n = hit_normal(S, w.r, w.best.ref);
+			F.hitO[slot] = make_float4(w.r.o.x, w.r.o.y, w.r.o.z, 0.0f);
+			F.hitD[slot] = make_float4(w.r.d.x, w.r.d.y, w.r.d.z, w.best.dist);
+			F.hitN[slot] = make_float4(n.x, n.y, n.z, __uint_as_float(w.best.ref));
+		}
+		if (has && !hit) {
+			// the path ends here: fold its light sums back to front, C = L_k + S_k * C (main.cpp:190), starting from Color()
+			// beyond the last hit (main.cpp:199) or the black background (main.cpp:124); quantise (Color.cpp:13-23)
+			f3 C = F3(0, 0, 0);
+			for (int k = (int)depth; k >= 0; --k) {
+				float4 L = make_float4(sum.x, sum.y, sum.z, __uint_as_float(matIndex));
+				if (k != (int)depth) L = F.litL[(size_t)k * F.nSlots + slot];
+				const float4 Sp = S.materials[(size_t)__float_as_uint(L.w) * 4 + 1];
+				if (reflections || k > 0) C = F3(L) + F3(Sp) * C;
+				else C = F3(L); // main.cpp:193
+			}
+			uint32_t px, py, inTile;
+			if (slot_to_pixel(F, slot, px, py, inTile)) {
+				const size_t o = out_offset(F, slot, px, py, inTile);
+				out[o] = quantise(C.z);     // B  main.cpp:154
+				out[o + 1] = quantise(C.y); // G
+				out[o + 2] = quantise(C.x); // R
+			}
+		}
+		const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
+		if (hm) {
+			nHitAll += (uint32_t)__popcll(hm);
+			nHitLast += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(hit && depth + 1u == last));
+			if (hit) myList[nbuf + (uint32_t)__popcll(hm & ltMask)] = slot | ((depth + 1u) << FRAME_SLOT_BITS);
+			nbuf += (uint32_t)__popcll(hm);
+		}
+		inBatch = false;
+	}
+	// statistics: a few atomics per wave
+	for (int off = 32; off > 0; off >>= 1) nShadowTraced += __shfl_down(nShadowTraced, off);
+	if (lane == 0) {
+		if (nShadowTraced) atomicAdd(F.counters + CTR_F_SHADOW_TRACED, nShadowTraced);
+		if (nHit0) atomicAdd(F.counters + CTR_F_HITS_PRIMARY, nHit0);
+		if (nHitAll) atomicAdd(F.counters + CTR_F_HITS_TOTAL, nHitAll);
+		if (nHitLast) atomicAdd(F.counters + CTR_F_HITS_LAST, nHitLast);
 	}
 }
 

@@ -10,9 +10,8 @@
 // the machine code of __powf_fma in libm.so.6 of glibc 2.35-0ubuntu3.11, constants read from the same file).
 // Double-precision add, multiply and FMA are IEEE on gfx950 as on x86-64, so the result is the same float.
 //
-// Covered exactly: x positive and finite (normal or subnormal), y finite and not zero, |y log2 x| < 126, and the
-// underflow range below it.  Everything else (zeros, infinities, NaNs, negative x, overflow) has an exact IEEE answer
-// that any conforming pow gives; the caller falls back to the generic one for those (powf_glibc returns false).
+// Every argument is covered: zeros, infinities, NaNs and negative bases are decided as glibc's code decides them (the C
+// standard's special cases), overflow and underflow return what its error paths return under round-to-nearest.
 #pragma once
 #include <stdint.h>
 #include <string.h>
@@ -60,15 +59,51 @@ MIRT_HD float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 MIRT_HD uint64_t d2u(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
 MIRT_HD double u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
 
-// Returns true and the power in `out` for the inputs described at the top, false otherwise.
-MIRT_HD bool powf_glibc(float x, float y, float& out) {
+// y as an integer: 0 = not an integer, 1 = odd, 2 = even
+MIRT_HD int checkint(uint32_t iy) {
+	const int e = (int)(iy >> 23 & 0xff);
+	if (e < 0x7f) return 0;
+	if (e > 0x7f + 23) return 2;
+	if (iy & ((1u << (0x7f + 23 - e)) - 1u)) return 0;
+	if (iy & (1u << (0x7f + 23 - e))) return 1;
+	return 2;
+}
+MIRT_HD bool issignaling(uint32_t i) { return 2u * (i ^ 0x00400000u) > 2u * 0x7fc00000u; }
+MIRT_HD bool zeroinfnan(uint32_t i) { return 2u * i - 1u >= 2u * 0x7f800000u - 1u; }
+
+// powf(x, y), every case (round-to-nearest, no errno): the special cases are the C standard's (Annex F), decided the way
+// glibc's code decides them.
+MIRT_HD float powf_glibc(float x, float y) {
 	uint32_t ix = f2u(x);
 	const uint32_t iy = f2u(y);
-	if (ix >= 0x7f800000u || ix == 0u) return false;                     // zero, negative, infinite, NaN
-	if (2u * iy - 1u >= 2u * 0x7f800000u - 1u) return false;            // y zero, infinite or NaN
-	if (ix < 0x00800000u) {                                              // subnormal x: normalise
-		ix = f2u(x * 0x1p23f) & 0x7fffffffu;
-		ix -= 23u << 23;
+	uint64_t sign_bias = 0;
+	if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || zeroinfnan(iy)) {
+		// either (x < 0x1p-126 or inf or nan) or (y is 0 or inf or nan)
+		if (zeroinfnan(iy)) {
+			if (2u * iy == 0u) return issignaling(ix) ? x + y : 1.0f;
+			if (ix == 0x3f800000u) return issignaling(iy) ? x + y : 1.0f;
+			if (2u * ix > 2u * 0x7f800000u || 2u * iy > 2u * 0x7f800000u) return x + y;
+			if (2u * ix == 2u * 0x3f800000u) return 1.0f;
+			if ((2u * ix < 2u * 0x3f800000u) == !(iy & 0x80000000u)) return 0.0f; // |x| < 1 && y == inf or |x| > 1 && y == -inf
+			return y * y;
+		}
+		if (zeroinfnan(ix)) {
+			float x2 = x * x;
+			if ((ix & 0x80000000u) && checkint(iy) == 1) x2 = -x2;
+			if (2u * ix == 0u && (iy & 0x80000000u)) return x2 == 0.0f && f2u(x2) == 0x80000000u ? -__builtin_inff() : __builtin_inff(); // 1 / +-0
+			return (iy & 0x80000000u) ? 1.0f / x2 : x2;
+		}
+		// x and y are non-zero finite
+		if (ix & 0x80000000u) { // finite x < 0
+			const int yint = checkint(iy);
+			if (yint == 0) return __builtin_nanf("");
+			if (yint == 1) sign_bias = 1ull << 16;
+			ix &= 0x7fffffffu;
+		}
+		if (ix < 0x00800000u) { // subnormal x: normalise
+			ix = f2u(u2f(ix) * 0x1p23f) & 0x7fffffffu;
+			ix -= 23u << 23;
+		}
 	}
 	// log2(x) = log1p(z/c - 1)/ln2 + log2(c) + k
 	const uint32_t tmp = ix - 0x3f330000u;
@@ -89,9 +124,9 @@ MIRT_HD bool powf_glibc(float x, float y, float& out) {
 	const double logx = __builtin_fma(ya, r4, q);
 	const double ylogx = (double)y * logx;
 	if (((d2u(ylogx) >> 47) & 0xffffu) >= (0x405f800000000000ull >> 47)) {   // |y log2 x| >= 126
-		if (ylogx > 0.0) return false;                                    // towards overflow: left to the generic pow
-		if (ylogx <= -150.0) { out = 0.0f; return true; }                // 0x1p-95f * 0x1p-95f
-		if (ylogx < -149.0) { out = 0x1p-149f; return true; }            // 0x1.4p-75f * 0x1.4p-75f, rounded to nearest
+		if (ylogx > 0x1.fffffffd1d571p+6) return sign_bias ? -__builtin_inff() : __builtin_inff();   // overflow
+		if (ylogx <= -150.0) return sign_bias ? -0.0f : 0.0f;                                         // 0x1p-95f * 0x1p-95f
+		if (ylogx < -149.0) return sign_bias ? -0x1p-149f : 0x1p-149f;                                // 0x1.4p-75f * 0x1.4p-75f
 	}
 	// 2^(k/32) 2^r with r in [-1/64, 1/64]
 	const double SHIFT = 0x1.8p+47;
@@ -99,14 +134,12 @@ MIRT_HD bool powf_glibc(float x, float y, float& out) {
 	const uint64_t ki = d2u(kd);
 	kd -= SHIFT;
 	const double rr = ylogx - kd;
-	const uint64_t t = EXP2_TAB[ki & 31u] + (ki << 47);
+	const uint64_t t = EXP2_TAB[ki & 31u] + ((ki + sign_bias) << 47);
 	const double s = u2d(t);
 	const double zz = __builtin_fma(0x1.c6af84b912394p-5, rr, 0x1.ebfce50fac4f3p-3);
 	const double rr2 = rr * rr;
 	const double yy = __builtin_fma(0x1.62e42ff0c52d6p-1, rr, 1.0);
-	const double res = __builtin_fma(zz, rr2, yy) * s;
-	out = (float)res;
-	return true;
+	return (float)(__builtin_fma(zz, rr2, yy) * s);
 }
 
 }  // namespace mirt_powf
