@@ -539,7 +539,7 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 		if (!single) HIPCHK(hipMemsetAsync(F.pathDepth, 0, n, st));
 	}
 	if (single) {
-		const int grid = s->numCUs * GRID_BLOCKS_PER_CU;
+		const int grid = s->numCUs * (MIRT_FRAME_WAVES < GRID_BLOCKS_PER_CU ? MIRT_FRAME_WAVES : GRID_BLOCKS_PER_CU); // every block resident at once
 		if (c) c->nLaunches = 0;
 		mark(s, c, st, -1);
 		if (effective_mode(s, p->trace_mode) == MODE_FAST) {
@@ -1033,7 +1033,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	if (!e) e = upload(s->sphInfo, sphInfo.data(), sphInfo.size() * 4);
 	if (!e) e = upload(s->materials, mats.data(), mats.size() * 4);
 	if (!e) e = upload(s->lights, lights.data(), lights.size() * 4);
-	if (!e) { e = s->dbg.ensure(16 * 8); if (!e) (void)hipMemset(s->dbg.p, 0, 16 * 8); }
+	if (!e) { e = s->dbg.ensure(32 * 8); if (!e) (void)hipMemset(s->dbg.p, 0, 32 * 8); }
 	ds.dbg = (unsigned long long*)s->dbg.p;
 	s->ovfStride = (uint32_t)s->numCUs * GRID_BLOCKS_PER_CU * BLOCK;
 	// the most entries a walk can hold: along any path, every node leaves behind all its children but one
@@ -1186,6 +1186,15 @@ int mirt_scene_query(mirt_scene* s, uint32_t what, uint64_t* v) {
 			break;
 		}
 #endif
+		if (what >= 140 && what < 156) { // k_frame timeline words of MIRT_STATS builds (read and clear), see k_frame
+			unsigned long long x = 0;
+			HIPCHK(hipSetDevice(s->device));
+			HIPCHK(hipDeviceSynchronize());
+			HIPCHK(hipMemcpy(&x, (char*)s->dbg.p + (16 + what - 140) * 8, 8, hipMemcpyDeviceToHost));
+			HIPCHK(hipMemset((char*)s->dbg.p + (16 + what - 140) * 8, 0, 8));
+			*v = x;
+			break;
+		}
 		if (what >= 100 && what < 116) { // diagnostic event counters of MIRT_STATS builds (read and clear)
 			unsigned long long x = 0;
 			HIPCHK(hipSetDevice(s->device));

@@ -122,11 +122,12 @@ struct DFrame {
 #define CTR_CURSOR(launch) (launch)              // 0..63  one dynamic-chunk cursor per kernel launch of the frame
 #define CTR_NHITS(depth) (64 + (depth))          // hits found at this depth
 #define CTR_NSHADOW(depth) (64 + 64 + (depth))   // shadow queries traced for the hits of this depth
-// k_frame (one launch per frame) uses the same block differently:
-#define CTR_F_PCUR 0            // next block of pixel slots to hand out
-#define CTR_F_HITS_PRIMARY 64   // == CTR_NHITS(0): primary rays that hit
-#define CTR_F_HITS_TOTAL 65     // hits at all depths
-#define CTR_F_HITS_LAST 66      // hits at the last depth (they spawn no reflection ray)
-#define CTR_F_SHADOW_TRACED 128 // == CTR_NSHADOW(0): shadow queries that were walked
+// k_frame (one launch per frame) uses the same block differently; words that many waves hammer lie 64 bytes apart:
+#define CTR_F_NCUR 8
+#define CTR_F_PCUR(k) (16 * (k)) // k < CTR_F_NCUR: block counters of the pixel slots (cursor k hands out blocks k, k + 8, ...)
+#define CTR_F_HITS_PRIMARY 160  // primary rays that hit
+#define CTR_F_HITS_TOTAL 161    // hits at all depths
+#define CTR_F_HITS_LAST 162     // hits at the last depth (they spawn no reflection ray)
+#define CTR_F_SHADOW_TRACED 163 // shadow queries that were walked
 #define CTR_COUNT 256
 #define FRAME_SLOT_BITS 27    // k_frame packs slot and depth into one word: fewer than 2^27 slots, depth <= 31

@@ -398,6 +398,9 @@ __device__ __forceinline__ uint32_t membership(const DScene& S, const RayCtx& r,
 #ifndef MIRT_REFILL_WAVES
 #define MIRT_REFILL_WAVES 7
 #endif
+#ifndef MIRT_FRAME_WAVES
+#define MIRT_FRAME_WAVES 7
+#endif
 
 // Traversal stack: STACK_LDS entries per lane in LDS ([entry][lane]: conflict-free, no address arithmetic beyond a
 // shift).  Hierarchies deeper than that (OVF = true, chosen by the host from the built depth) keep the deeper entries in
@@ -1126,10 +1129,18 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DFrame F, uint8_t* __restrict
 //     pixel is written.
 // Per-path data: one hit record per slot (the record of depth d is dead once its lane has written the record of depth
 // d+1 over it) and one light sum per slot and depth; both are written and read by the same wave only.
+//
+// The end of a wave's work: when the slots have run out it works on what is left in its list, however few hits that is,
+// round after round with most lanes idle.  Pooling such left-overs was measured twice and dropped: among the four waves
+// of a block (in LDS; a wave leaves its hits to those still at work) the frame rate FELL by 7 % and a frame alone took
+// 11 % longer, because the left-overs of four waves then pass through one wave, one batch after the other; in one pool
+// for the whole launch (global memory, compare-and-swap on a cursor) thousands of waves polling two words made a 4K
+// frame take 70 ms.  At the end of a frame, waves working side by side on little beat fewer waves working on more.
 #define FRAME_SLOT_MASK ((1u << FRAME_SLOT_BITS) - 1u)
+#define FRAME_EMPTY 0xffffffffu
 
 template <int MODE, bool OVF>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_BATCH_WAVES))) void k_frame(DScene S, DFrame F, uint8_t* __restrict__ out) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_FRAME_WAVES))) void k_frame(DScene S, DFrame F, uint8_t* __restrict__ out) {
 	__shared__ uint32_t s_stack[STACK_LDS * BLOCK];
 	__shared__ uint32_t s_list[BLOCK / WAVE][128];
 	LdsStack<OVF, STACK_LDS> stk;
@@ -1143,26 +1154,41 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_BATC
 	const bool reflections = (F.features & F_REFLECTIONS) != 0;
 	const bool shadows = (F.features & F_SHADOWS) != 0;
 	const uint32_t last = reflections ? (uint32_t)S.maxDepth : 0u; // deepest hit a path can have (main.cpp:177)
-	// pixel slots come in blocks: a wave's first block is its own, later ones come from the cursor (one atomic per block; a
-	// single address sustains only ~88 atomics per microsecond).  Blocks shrink towards the end of the slots, so that the
-	// last paths to start are spread over many waves.
+	// Pixel slots come 64 at a time (one batch: the finer the grain, the later a wave can still be given the next batch
+	// instead of sitting on a long queue of its own).  A wave's first batch is its own; later ones come from CTR_F_NCUR
+	// counters that hand out the batch numbers in turn -- one address sustains only ~88 atomics per microsecond, a 4K frame has
+	// 130 000 batches.  A wave starts at one counter and moves on to the next when that one has run out.
 	const uint32_t nWaves = gridDim.x * (BLOCK / WAVE);
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
-	const uint32_t per0 = F.nSlots / (2u * nWaves);
-	const uint32_t blk0 = per0 >= 256u ? 256u : (per0 >= 128u ? 128u : 64u);
-	uint32_t pb = wave * blk0, pe = pb + blk0, blk = blk0;
-	uint32_t nShadowTraced = 0;   // per lane
+	const uint32_t nBatches = (F.nSlots + 63u) >> 6;
+	// (The number of the next batch is fetched only when the wave is ready for it: fetched ahead, every wave holds back one
+	// batch while it works on the hits of another, and the frame ends a whole batch's chain of rounds later.)
+	uint32_t pbatch = wave;       // the batch of slots to do next; >= nBatches: to be fetched, or none left
+	bool pfirst = true;           // pbatch is the wave's own first batch
+	uint32_t pcur = wave % CTR_F_NCUR, pcurTried = 0;
+	uint32_t nShadowTraced = 0;   // per wave
 	uint32_t nHit0 = 0, nHitAll = 0, nHitLast = 0; // per wave
+#if MIRT_STATS || MIRT_TIMELINE
+	// timeline of the launch in ticks of the constant 100 MHz clock: S.dbg[16..] = first start (stored as ~t for atomicMax),
+	// last end, first and last time a wave found the slots exhausted, summed wave lifetimes, summed time after exhaustion, waves
+	const unsigned long long tStart = wall_clock64();
+	unsigned long long tExhausted = 0;
+	uint32_t nRounds = 0, nLaneRounds = 0;
+#endif
 	Walker<MODE, OVF> w;
 	// The wave works in rounds; every round is: set up to 64 rays, walk them (ONE copy of the walk in the kernel), use the
 	// answers.  ROUND_PRIMARY: 64 camera rays.  A batch of hits takes ROUND_LIGHT once per light, then ROUND_REFLECT.
+	// (Measured and dropped: at the end of a wave's work, when the hits that are left and all their rays fit into the 64 lanes
+	// at once, one merged round per depth -- reflection rays in the first lanes, shadow queries in the others, answers passed
+	// through LDS.  Two rounds fewer per wave, but the larger kernel spills more registers in every round: a frame alone 6 %
+	// slower, eight frames in flight 12 % slower.)
 	enum { ROUND_PRIMARY, ROUND_LIGHT, ROUND_REFLECT };
 	int round = ROUND_PRIMARY;
 	uint32_t li = 0;              // the light of ROUND_LIGHT
-	uint32_t entry = 0xffffffffu; // this lane's hit of the current batch (slot | depth << 27), or none
+	uint32_t entry = FRAME_EMPTY; // this lane's hit of the current batch (slot | depth << 27), or none
 	uint32_t tag = 0;             // ROUND_PRIMARY: this lane's slot
-	f3 sum = F3(0, 0, 0);         // the hit's light sum so far (main.cpp:204-253)
-	uint32_t matIndex = 0;
+	// (the hit's light sum so far, main.cpp:204-253, and its material index wait in F.litL while the rays are walked: four
+	// registers less to carry through the walk)
 	bool inBatch = false;         // a batch of hits is being worked on
 	for (;;) {
 		// ---- which round, and its rays --------------------------------------------------------------------------------
@@ -1171,22 +1197,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_BATC
 		w.best.ref = REF_NONE;
 		w.best.dist = __builtin_inff();
 		if (!inBatch) {
-			if (nbuf < 64u && pb >= pe && pb < F.nSlots) {
-				uint32_t c = 0;
-				if (lane == 0) c = atomicAdd(F.counters + CTR_F_PCUR, blk);
-				pb = __builtin_amdgcn_readfirstlane(c) + nWaves * blk0;
-				pe = pb + blk;
-				const uint32_t rest = pe < F.nSlots ? F.nSlots - pe : 0u, per = rest / (2u * nWaves);
-				blk = per >= 256u ? 256u : (per >= 128u ? 128u : 64u);
-				if (blk > blk0) blk = blk0;
+			if (nbuf < 64u && !pfirst) {
+				pbatch = nBatches;
+				while (pcurTried < CTR_F_NCUR) {
+					uint32_t t = 0;
+					if (lane == 0) t = atomicAdd(F.counters + CTR_F_PCUR(pcur), 1u);
+					const uint32_t b = nWaves + pcur + CTR_F_NCUR * __builtin_amdgcn_readfirstlane(t);
+					if (b < nBatches) { pbatch = b; break; }
+					pcur = (pcur + 1u) % CTR_F_NCUR;
+					++pcurTried;
+				}
 			}
-			if (nbuf < 64u && pb < pe && pb < F.nSlots) {
+			if (nbuf < 64u && pbatch < nBatches) {
 				// up to 64 camera rays (main.cpp:152-153, depth 0)
 				round = ROUND_PRIMARY;
-				const uint32_t end = pe < F.nSlots ? pe : F.nSlots;
-				const uint32_t got = end - pb < 64u ? end - pb : 64u;
-				tag = pb + (uint32_t)lane;
-				pb += got;
+				pfirst = false;
+				tag = pbatch * 64u + (uint32_t)lane;
+				const uint32_t got = F.nSlots - pbatch * 64u < 64u ? F.nSlots - pbatch * 64u : 64u;
 				if ((uint32_t)lane < got) {
 					uint32_t px, py, inTile;
 					if (slot_to_pixel(F, tag, px, py, inTile)) { // false: padding pixel of an edge tile
@@ -1198,22 +1225,29 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_BATC
 				}
 			}
 			else {
-				if (nbuf == 0u) break; // no slots left and no hits left: this wave is done
 				// up to 64 hits: their lights, then their reflection rays (main.cpp:187-190)
-				const uint32_t take = nbuf < 64u ? nbuf : 64u;
-				nbuf -= take;
-				entry = (uint32_t)lane < take ? myList[nbuf + (uint32_t)lane] : 0xffffffffu;
-				if (entry != 0xffffffffu) {
-					matIndex = info_of(S, __float_as_uint(F.hitN[entry & FRAME_SLOT_MASK].w)).y;
+				if (nbuf >= 64u) {
+					nbuf -= 64u;
+					entry = myList[nbuf + (uint32_t)lane];
+				}
+				else {
+					// no slots left: the rest of the list, however little it is
+					if (nbuf == 0u) break; // this wave is done
+					entry = (uint32_t)lane < nbuf ? myList[lane] : FRAME_EMPTY;
+					nbuf = 0;
+				}
+				if (entry != FRAME_EMPTY) {
+					const uint32_t matIndex = info_of(S, __float_as_uint(F.hitN[entry & FRAME_SLOT_MASK].w)).y;
 					const float4* mat = S.materials + (size_t)matIndex * 4;
-					sum = F3(mat[3]) + F3(mat[2]);                           // main.cpp:204: ambient + emission
+					const f3 sum = F3(mat[3]) + F3(mat[2]);                  // main.cpp:204: ambient + emission
+					F.litL[(size_t)(entry >> FRAME_SLOT_BITS) * F.nSlots + (entry & FRAME_SLOT_MASK)] = make_float4(sum.x, sum.y, sum.z, __uint_as_float(matIndex));
 				}
 				inBatch = true;
 				li = 0;
 				round = S.nLights ? ROUND_LIGHT : ROUND_REFLECT;
 			}
 		}
-		const bool has = inBatch && entry != 0xffffffffu;
+		const bool has = inBatch && entry != FRAME_EMPTY;
 		const uint32_t slot = entry & FRAME_SLOT_MASK, depth = has ? entry >> FRAME_SLOT_BITS : 0u;
 		if (inBatch && round == ROUND_LIGHT) {
 			if (has && shadows) {                                            // main.cpp:208-224
@@ -1237,10 +1271,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_BATC
 					const float atten = ll.w > 0.0f ? 1.0f / (S.atten[0] + S.atten[1] * dl + S.atten[2] * (dl * dl)) : 1.0f;
 					if (kd0 && ks0 && fabsf(atten) <= 1e15f) walk = false;
 				}
-				if (walk) {
-					++nShadowTraced;
-					w.start(S, P, dir, F.debug == D_SHADOW_MAP ? -2.0f : dl); // :223-224 (SHADOW_MAP wants the nearest occluder)
-				}
+				if (walk) w.start(S, P, dir, F.debug == D_SHADOW_MAP ? -2.0f : dl); // :223-224 (SHADOW_MAP wants the nearest occluder)
 			}
 		}
 		else if (inBatch) { // ROUND_REFLECT: a path goes on while depth + 1 <= maxDepth (main.cpp:177,189-190)
@@ -1254,6 +1285,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_BATC
 		}
 		// ---- the walk ------------------------------------------------------------------------------------------------
 		const unsigned long long walked = __builtin_amdgcn_ballot_w64(walk);
+		if (inBatch && round == ROUND_LIGHT) nShadowTraced += (uint32_t)__popcll(walked);
+#if MIRT_STATS || MIRT_TIMELINE
+		if (pbatch >= nBatches && !tExhausted) tExhausted = wall_clock64();
+		if (walked) { ++nRounds; nLaneRounds += (uint32_t)__popcll(walked); }
+#endif
 		if (walked) {
 			walk_wave<false, false>(S, w, stk);
 			// deferred check of the final answers; the rare ray that fails it is walked again, strictly
@@ -1300,14 +1336,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_BATC
 				const float4 ho = F.hitO[slot], hd = F.hitD[slot], hn = F.hitN[slot];
 				const f3 po = F3(ho);
 				const f3 P = po + normalize3(F3(hd)) * hd.w;
-				shade_light(S, F.features, F.debug, po, P, F3(hn), S.materials + (size_t)matIndex * 4, li, shadows,
+				float4* lit = F.litL + (size_t)depth * F.nSlots + slot;
+				const float4 l4 = *lit;
+				f3 sum = F3(l4);
+				shade_light(S, F.features, F.debug, po, P, F3(hn), S.materials + (size_t)__float_as_uint(l4.w) * 4, li, shadows,
 				            hit ? w.best.ref : REF_NONE, hit ? w.best.dist : __builtin_inff(), sum);
+				*lit = make_float4(sum.x, sum.y, sum.z, l4.w);
 			}
 			if (++li >= S.nLights) round = ROUND_REFLECT;
 			continue;
 		}
-		// ROUND_REFLECT: the hit's light sum is complete
-		if (has) F.litL[(size_t)depth * F.nSlots + slot] = make_float4(sum.x, sum.y, sum.z, __uint_as_float(matIndex));
+		// ROUND_REFLECT: the hit's light sum is complete (in F.litL)
 		if (hit) {
 			const f3 n = hit_normal(S, w.r, w.best.ref);
 			F.hitO[slot] = make_float4(w.r.o.x, w.r.o.y, w.r.o.z, 0.0f);
@@ -1319,8 +1358,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_BATC
 			// beyond the last hit (main.cpp:199) or the black background (main.cpp:124); quantise (Color.cpp:13-23)
 			f3 C = F3(0, 0, 0);
 			for (int k = (int)depth; k >= 0; --k) {
-				float4 L = make_float4(sum.x, sum.y, sum.z, __uint_as_float(matIndex));
-				if (k != (int)depth) L = F.litL[(size_t)k * F.nSlots + slot];
+				const float4 L = F.litL[(size_t)k * F.nSlots + slot];
 				const float4 Sp = S.materials[(size_t)__float_as_uint(L.w) * 4 + 1];
 				if (reflections || k > 0) C = F3(L) + F3(Sp) * C;
 				else C = F3(L); // main.cpp:193
@@ -1342,8 +1380,22 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_BATC
 		}
 		inBatch = false;
 	}
+#if MIRT_STATS || MIRT_TIMELINE
+	if (lane == 0) {
+		const unsigned long long tEnd = wall_clock64();
+		if (!tExhausted) tExhausted = tEnd;
+		atomicMax(S.dbg + 16, ~tStart);
+		atomicMax(S.dbg + 17, tEnd);
+		atomicMax(S.dbg + 18, ~tExhausted);
+		atomicMax(S.dbg + 19, tExhausted);
+		atomicAdd(S.dbg + 20, tEnd - tStart);
+		atomicAdd(S.dbg + 21, tEnd - tExhausted);
+		atomicAdd(S.dbg + 22, 1ull);
+		atomicAdd(S.dbg + 23, (unsigned long long)nRounds);
+		atomicAdd(S.dbg + 24, (unsigned long long)nLaneRounds);
+	}
+#endif
 	// statistics: a few atomics per wave
-	for (int off = 32; off > 0; off >>= 1) nShadowTraced += __shfl_down(nShadowTraced, off);
 	if (lane == 0) {
 		if (nShadowTraced) atomicAdd(F.counters + CTR_F_SHADOW_TRACED, nShadowTraced);
 		if (nHit0) atomicAdd(F.counters + CTR_F_HITS_PRIMARY, nHit0);

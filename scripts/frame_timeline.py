@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Diagnostic (a -DMIRT_TIMELINE=1 build of mirt_api.hip as exp/libmirt_timeline.so): where the time of ONE k_frame launch goes.
+Prints, in microseconds from the first wave's start: when the pixel slots ran out (first / last wave to notice), when the last
+wave ended, the mean wave lifetime and the mean time a wave spent after the slots had run out, rounds and lane use."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raytracer_amd import _capi, workloads
+from raytracer_amd.device import DeviceScene
+from raytracer_amd.scene import FlatScene
+w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 2160)
+lib = _capi.load_library(os.environ.get("MIRT_TIMELINE_LIB") or os.path.join(ROOT, "exp", "libmirt_timeline.so"))  # -DMIRT_TIMELINE=1 build
+flat = FlatScene.from_text(workloads.dragon(w, h))
+def q(s, k):
+    v = C.c_uint64()
+    assert lib.mirt_scene_query(s.h, k, C.byref(v)) == 0
+    return v.value
+with DeviceScene(flat, 0, lib=lib) as s:
+    s.render(w, h)
+    for k in range(140, 149): q(s, k)
+    _, st = s.render(w, h)
+    t0 = (~q(s, 140)) & (2**64 - 1); tend = q(s, 141); ex0 = (~q(s, 142)) & (2**64 - 1); ex1 = q(s, 143)
+    life, tail, waves, rounds, lanes = (q(s, k) for k in range(144, 149))
+    us = lambda t: t / 100.0
+    print("device_ms %.3f; slots exhausted at %.0f .. %.0f us, last wave ended at %.0f us" % (st["device_ms"], us(ex0 - t0), us(ex1 - t0), us(tend - t0)))
+    print("waves %d, mean lifetime %.0f us, mean time after exhaustion %.0f us, rounds per wave %.1f, lanes per round %.1f" % (waves, us(life / waves), us(tail / waves), rounds / waves, lanes / max(1, rounds)))
