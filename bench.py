@@ -2,19 +2,20 @@
 """Headline benchmark: Mrays/s (primary + shadow + reflection) of the trace path on the Stanford Dragon scene.
 
   python bench.py --gpus 1 --steps K --warmup W          Dragon 3840x2160, maxdepth 5, all features, one MI355X
-  torchrun ... bench.py --gpus N ...                       Dragon 7680x4320 cut into interleaved tiles over N GPUs,
+  torchrun ... bench.py --gpus N ...                       the same frame cut into interleaved tiles over N GPUs,
                                                            RCCL gather of the tile buffers + reassembly on rank 0
+  --workload dragon8k | cornell | spheres | grid           the other BASELINE configurations (extra measurements)
 
-A step is one frame: every kernel of the path (primary, per-depth trace/shade, resolve) over the whole image, scene and
-framebuffer resident in HBM.  Rank 0 prints ONE JSON line.  Rays are counted the way the reference's control flow spawns
-them (RayTracer/main.cpp:176-223): primary = pixels, shadow = lights x hits at every depth, reflection = hits at depth
-d < maxdepth.
+A step is one frame: every kernel of the path over the whole image, scene and framebuffer resident in HBM; frames are
+issued round-robin on several streams (frames in flight).  After the timed loop the last frame of every stream is compared
+byte for byte with a frame rendered alone, and the synchronous host call's image with that; no line is printed otherwise.
+Rank 0 prints ONE JSON line.  Rays are counted the way the reference's control flow spawns them
+(RayTracer/main.cpp:176-223): primary = pixels, shadow = lights x hits at every depth, reflection = hits at depth < maxdepth.
 
-The `cpu_baseline` leg (rank 0, N = 1 only) times the reference's own compiled classes (oracle/_ref, kind "reference")
-or, if that build is absent, the C restatement (kind "port") on a bounded row sample of the same image, one thread.
-The `roofline` object prices the frame against HBM bandwidth with ALGORITHMIC bytes: the reference's exhaustive tree
-walk's box tests x 32 B + primitive tests x 40 B (112+4 for spheres) + 32 B ray state, per ray kind, measured by the
-oracle's visit counters on the same row sample.
+Beside `value` the line carries `frame_alone_ms` (one frame, nothing else on the GPU), `sync_host_ms` (mirt_render: the
+call that replaces main.cpp:137-163, host buffer out), `roofline` (see roofline()) and `cpu_baseline` (rank 0, N = 1: the
+reference's own compiled classes, oracle/_ref, kind "reference" -- or the C restatement, kind "port" -- on a bounded row
+sample of the same image, one thread, plus what 16 processes of it reach together).
 """
 import argparse
 import json
@@ -93,6 +94,97 @@ def cpu_baseline_and_visits(flat, scene_text, width, height, row_step, use_refer
         except Exception as exc:  # the one-core figure above is the baseline; this one is an extra
             base["all_cores"] = {"error": str(exc)[:200]}
     return base, st["visits"], rays
+
+
+def device_walk_counts(flat, dev_index, width, height, trace_mode):
+    """One frame through the statistics build of the library (raytracer_amd/libmirt_stats.so: same kernels with event
+    counters, far slower, never timed): what the device walk really does."""
+    import ctypes as C
+    from raytracer_amd import _capi
+    from raytracer_amd.device import DeviceScene
+    path = os.path.join(ROOT, "raytracer_amd", "libmirt_stats.so")
+    if not os.path.exists(path):
+        return None
+    lib = _capi.load_library(path)
+
+    def q(s, k):
+        v = C.c_uint64()
+        return int(v.value) if lib.mirt_scene_query(s.h, k, C.byref(v)) == 0 else 0
+    with DeviceScene(flat, dev_index, lib=lib) as s:
+        for k in (101, 103, 105, 116, 118, 119):
+            q(s, k)  # read and clear
+        _, st = s.render(width, height, trace_mode=trace_mode)
+        c = {"node_steps": q(s, 101), "primitive_tests": q(s, 103), "membership_checks": q(s, 105), "triangle_fallbacks": q(s, 116),
+             "stack_pushes": q(s, 117), "stack_pushes_overflow": q(s, 118), "membership_boxes": q(s, 119)}
+        c["hits"] = (st["shadow_rays"] // max(1, flat.lights.shape[0])) if flat.lights.shape[0] else st["primary_hits"]
+    return c
+
+
+def roofline(scene, flat, args, width, height, trace_mode, rays, vis, srays, kern, kern_alone, step_s):
+    """HBM roofline of the dominant kernel (the launches that walk the scene).
+
+    achieved = ALGORITHMIC bytes of the DEVICE's walk per frame / duration of those launches for a frame rendered ALONE
+    (HIP events on the launch stream).  The bytes are what the lanes ask the memory system for, counted by the statistics
+    build on the same frame: 64 B per node step (one four-child node), 64 B per triangle test (144 B per sphere test), 32 B
+    per triangle test that falls back to the reference's own inside test, 16 + 32 B per leaf box of a membership check,
+    4 B per traversal-stack push beyond LDS and 4 B per pop, and per hit: 48 B record written and read once per light
+    set-up, per light shading and per reflection set-up, a 16-B light sum read and written per light and read once more
+    by the fold, 64 B of material; 3 B per pixel cleared, 3 B per pixel written.  The Dragon is cache resident (HBM
+    `traffic` is a small fraction of this), so this is a demand figure against the HBM peak, not a claim of HBM use; the
+    kernel's real limiter, VALU issue under divergence, is priced in `valu_issue` from the PMC pass under profiles/.
+    The reference's exhaustive walk priced the same way (box tests x 32 B + primitive tests x 40 B + 32 B ray state,
+    visit counts from the oracle on the CPU sample) is kept beside it as `reference_walk`."""
+    nl = int(flat.lights.shape[0])
+    tri = flat.tri_verts.shape[0] >= flat.spheres.shape[0]
+    walk_kinds = ("primary", "trace", "shade", "frame")
+    ms_alone = sum(kern_alone[k]["ms_per_frame"] for k in walk_kinds if k in kern_alone)
+    ms_pipe = sum(kern[k]["ms_per_frame"] for k in walk_kinds if k in kern)
+    n_launch = sum(kern_alone[k]["launches_per_frame"] for k in walk_kinds if k in kern_alone)
+    c = device_walk_counts(flat, scene.device, width, height, trace_mode)
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    if c:
+        hits = c["hits"]
+        b = (64.0 * c["node_steps"] + (64.0 if tri else 144.0) * c["primitive_tests"] + 32.0 * c["triangle_fallbacks"]
+             + 16.0 * c["membership_checks"] + 32.0 * c["membership_boxes"] + 8.0 * c["stack_pushes_overflow"]
+             + hits * (48.0 + 16.0 + 64.0 + nl * (48.0 + 48.0 + 32.0) + 48.0 + 16.0 + 16.0)
+             + 3.0 * width * height + 3.0 * float(rays[0]))
+        out.update({"achieved": b / (ms_alone * 1e-3) / 1e9, "frac": b / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_frame": b, "device_walk_counts": c,
+                    "per_ray": {"node_steps": c["node_steps"] / float(rays[0] + rays[3] + rays[4]), "primitive_tests": c["primitive_tests"] / float(rays[0] + rays[3] + rays[4])}})
+    else:
+        out.update({"achieved": None, "frac": None, "note_counts": "raytracer_amd/libmirt_stats.so not built: no device-walk counts"})
+    out["kernel"] = "%d launch(es) per frame that walk the scene (%s)" % (n_launch, ", ".join(k for k in walk_kinds if k in kern_alone))
+    out["launch_ms_alone"] = ms_alone
+    out["launch_ms_in_pipeline"] = ms_pipe
+    # HBM traffic, VALU issue and lane use come from rocprofv3 --pmc passes (they cannot be read from inside this process):
+    # scripts/profile_round.sh runs them over one frame of this workload and leaves the summary under profiles/
+    out["traffic"] = None
+    ppath = os.path.join(ROOT, "profiles", "r02", "pmc_frame.json")
+    if args.workload == "dragon" and (width, height) == (3840, 2160) and os.path.exists(ppath):
+        pmc = json.load(open(ppath))
+        out["traffic"] = pmc.get("hbm_bytes_per_frame")
+        out["traffic_note"] = "HBM bytes of one frame alone: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950: it tallies 128-B requests at 64 B) + WRITE_SIZE, KB x 1024, separate passes; profiles/r02/pmc_frame.json"
+        if pmc.get("valu_insts_per_frame") and pmc.get("kernel_ms"):
+            simds, clock = 1024, 2.4e9
+            # gfx950's SIMDs are 32 lanes wide: with several waves resident a SIMD issues one wave64 VALU instruction per 2 cycles
+            cyc = 2
+            out["valu_issue"] = {"bound": "valu issue", "insts_per_frame": pmc["valu_insts_per_frame"], "cycles_per_inst": cyc, "simds": simds, "clock_hz": clock,
+                                 "frac_alone": pmc["valu_insts_per_frame"] * cyc / (simds * clock * ms_alone * 1e-3),
+                                 "frac_per_step": pmc["valu_insts_per_frame"] * cyc / (simds * clock * step_s),
+                                 "lane_utilisation": pmc.get("valu_lane_util"), "wait_frac": pmc.get("wait_frac"),
+                                 "note": "wave-level VALU instructions of one frame (SQ_INSTS_VALU) x 2 issue cycles (SIMD-32) over 1024 SIMDs x 2.4 GHz x time: over the launch of a frame alone, and over ms_per_step with frames in flight; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES"}
+    # the reference's exhaustive walk priced in bytes and flops, from the oracle's visit counters on the CPU sample
+    per_ray = []
+    for k in range(3):
+        n = max(int(srays[k]), 1)
+        per_ray.append((float(vis[k][0]) * NODE_BYTES + float(vis[k][2]) * (TRI_BYTES if tri else SPHERE_BYTES)) / n + RAY_STATE_BYTES)
+    ref_bytes = float(rays[0]) * per_ray[0] + float(rays[1]) * per_ray[1] + float(rays[2]) * per_ray[2] + width * height * 3
+    prim_flops = TRI_FLOPS if tri else SPHERE_FLOPS
+    ref_flops = sum(float(rays[k]) * (float(vis[k][0]) * NODE_FLOPS + float(vis[k][2]) * prim_flops) / max(int(srays[k]), 1) for k in range(3))
+    out["reference_walk"] = {"note": "side figure: the bytes and flops the reference's exhaustive tree walk would need for this frame; the device walk is ordered, culled and de-duplicated, so a rate against these exceeds what the device does",
+                             "bytes_per_ray": {"primary": per_ray[0], "shadow": per_ray[1], "reflection": per_ray[2]}, "bytes_per_frame": ref_bytes, "flops_per_frame": ref_flops,
+                             "GBs_per_step": ref_bytes / step_s / 1e9, "TFLOPs_per_step": ref_flops / step_s / 1e12, "fp32_vector_peak_TFLOPs": FP32_PEAK_TFLOPS}
+    return out
 
 
 def main():
@@ -214,9 +306,29 @@ def main():
     # (a) launch durations INSIDE the timed region: the last frame of every stream (frames overlap, so a launch shares the GPU)
     used = [streams[(frame_no[0] - 1 - i) % depth] for i in range(min(depth, args.steps))]  # streams of the last timed frames
     kern = collect([scene.launch_times(s_.cuda_stream) for s_ in used])
-    # (b) the same launches with nothing else on the GPU, outside the timed region
-    kern_alone = collect([(scene.render_device(params, local.data_ptr(), nbytes, stream), scene.launch_times(stream))[1] for _ in range(5)])
+    # (b) frames ALONE, outside the timed region: one at a time, nothing else on the GPU.  Launch durations from the same HIP
+    # events; frame_alone_ms = first clear to last launch of the frame (the library's own pair of events on the stream)
+    alone_lt, alone_ms = [], []
+    for _ in range(7):
+        scene.render_device(params, local.data_ptr(), nbytes, stream)
+        alone_lt.append(scene.launch_times(stream))
+        alone_ms.append(scene.stats(stream)["device_ms"])
+    kern_alone = collect(alone_lt)
+    frame_alone_ms = float(np.median(alone_ms))
     scene.set_profiling(False)
+    # (c) the boundary's own synchronous call: mirt_render into host memory, what replaces main.cpp:137-163 as it stands
+    sync_host_ms = None
+    if world == 1:
+        host_img = np.zeros((height, width, 3), np.uint8)
+        scene.render(width, height, trace_mode=trace_mode, out=host_img)
+        ts = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            scene.render(width, height, trace_mode=trace_mode, out=host_img)
+            ts.append((time.perf_counter() - t1) * 1e3)
+        sync_host_ms = float(np.median(ts))
+        if not np.array_equal(host_img.reshape(-1), check.cpu().numpy()):
+            raise SystemExit("bench self-check FAILED: mirt_render's host image differs from the device frame")
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo else "cuda")
@@ -246,47 +358,17 @@ def main():
             "rays_per_frame": {"primary": int(rays[0]), "shadow": int(rays[1]), "reflection": int(rays[2])},
             "rays_walked_per_frame": {"primary": int(rays[0]), "shadow": int(rays[3]), "reflection": int(rays[4])},
             "self_check": "last frame of each of the %d streams byte-equal to a frame rendered alone" % depth,
-            "kernels": kern,
-            "kernels_alone": kern_alone,
+            "frame_alone_ms": frame_alone_ms,   # one frame with nothing else on the GPU: clears + every launch
+            "sync_host_ms": sync_host_ms,       # mirt_render: the same plus the copy into the caller's host buffer, host clock
+            "kernels": kern,                    # launch durations inside the timed region (launches of frames in flight share the GPU)
+            "kernels_alone": kern_alone,        # the same launches of a frame rendered alone
         }
-        frame_ms = sum(k["ms_per_frame"] for k in kern.values())
-        out["device_ms_per_frame"] = frame_ms
         if world == 1 and not args.no_cpu_baseline:
             row_step = args.cpu_row_step or (128 if args.workload == "grid" else 16)
             # the reference needs minutes to load the 10 M triangle grid: that workload is timed on the C restatement
             base, vis, srays = cpu_baseline_and_visits(flat, scene_text, width, height, row_step, use_reference=args.workload != "grid")
             out["cpu_baseline"] = base
-            # algorithmic bytes per ray kind from the exhaustive walk's visit counts on the sample
-            per_ray = []
-            for k in range(3):
-                n = max(int(srays[k]), 1)
-                per_ray.append((float(vis[k][0]) * NODE_BYTES + float(vis[k][2]) * (TRI_BYTES if flat.tri_verts.shape[0] >= flat.spheres.shape[0] else SPHERE_BYTES)) / n + RAY_STATE_BYTES)
-            frame_bytes = float(rays[0]) * per_ray[0] + float(rays[1]) * per_ray[1] + float(rays[2]) * per_ray[2] + width * height * 3
-            # the same visit counts priced in flops (box test 24, triangle test 60, sphere test 120): the secondary roofline
-            prim_flops = (TRI_FLOPS if flat.tri_verts.shape[0] >= flat.spheres.shape[0] else SPHERE_FLOPS)
-            frame_flops = sum(float(rays[k]) * (float(vis[k][0]) * NODE_FLOPS + float(vis[k][2]) * prim_flops) / max(int(srays[k]), 1) for k in range(3))
-            # dominant kernels: everything that walks the tree (primary + trace + shade); resolve is the remainder
-            walk_ms = sum(kern[k]["ms_per_frame"] for k in ("primary", "trace", "shade", "frame") if k in kern)
-            achieved = frame_bytes / (walk_ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01", "hbm_traffic.json")
-            if args.workload == "dragon" and (width, height) == (3840, 2160) and os.path.exists(tpath):  # PMC counters cannot be read from inside this process; separate rocprofv3 --pmc passes
-                traffic = json.load(open(tpath))["hbm_bytes_per_frame"]
-            out["roofline"] = {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "k_trace (+ k_shade): the launches of one frame that walk the scene, %d launches; durations = HIP events in the timed region" % sum(kern[k]["launches_per_frame"] for k in ("primary", "trace", "shade", "frame") if k in kern),
-                "algorithmic_bytes_per_ray": {"primary": per_ray[0], "shadow": per_ray[1], "reflection": per_ray[2]},
-                "algorithmic_bytes_per_frame": frame_bytes,
-                "traffic_note": "HBM bytes of one frame from rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/r01/hbm_traffic.json",
-                "note": "bytes = reference-semantics exhaustive walk (box tests x32 B + triangle tests x40 B + 32 B ray state); the device walk is ordered and culled, so it touches far fewer",
-                # launches of the frames in flight share the GPU, so their event durations add up to more than a frame's
-                # share of the wall clock; the same bytes over ms_per_step and over the launches of a frame run alone:
-                "secondary": {"bound": "fp32 vector", "achieved": frame_flops / (walk_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": frame_flops / (walk_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "algorithmic_flops_per_frame": frame_flops,
-                              "achieved_per_step": frame_flops / (elapsed / args.steps) / 1e12},
-                "achieved_per_step_GBs": frame_bytes / (elapsed / args.steps) / 1e9,
-                "achieved_frame_alone_GBs": frame_bytes / (sum(kern_alone[k]["ms_per_frame"] for k in ("primary", "trace", "shade", "frame") if k in kern_alone) * 1e-3) / 1e9,
-            }
+            out["roofline"] = roofline(scene, flat, args, width, height, trace_mode, rays, vis, srays, kern, kern_alone, elapsed / args.steps)
         print(json.dumps(out), flush=True)
     scene.close()
     if world > 1:

@@ -1176,6 +1176,15 @@ int mirt_scene_query(mirt_scene* s, uint32_t what, uint64_t* v) {
 			*v = x;
 			break;
 		}
+		if (what == 119) { // leaf boxes tested by the membership check (read and clear)
+			unsigned long long x = 0, z = 0;
+			HIPCHK(hipSetDevice(s->device));
+			HIPCHK(hipDeviceSynchronize());
+			HIPCHK(hipMemcpyFromSymbol(&x, HIP_SYMBOL(g_statMembEntries), 8));
+			HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_statMembEntries), &z, 8));
+			*v = x;
+			break;
+		}
 		if (what == 117 || what == 118) { // traversal-stack pushes: all / to the overflow area (read and clear)
 			unsigned long long x[2] = {0, 0}, z[2] = {0, 0};
 			HIPCHK(hipSetDevice(s->device));

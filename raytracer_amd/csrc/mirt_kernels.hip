@@ -159,6 +159,7 @@ __device__ __forceinline__ bool box_hit(const RayCtx& r, const f3& e, f3 lo, f3 
 #if MIRT_STATS
 __device__ unsigned long long g_statFallback[1];
 __device__ unsigned long long g_statPush[2]; // traversal-stack pushes: all, and those that went to the global overflow area
+__device__ unsigned long long g_statMembEntries[1]; // leaf boxes tested by membership()
 #endif
 template <int MODE>
 __device__ __forceinline__ float tri_hit(const RayCtx& r, const float4* __restrict__ T, const float4* __restrict__ X, float tcull) {
@@ -373,6 +374,9 @@ __device__ __forceinline__ uint32_t membership(const DScene& S, const RayCtx& r,
 	const float4* m = S.memb + (size_t)ofs * 2;
 	const f3 e = box_dir(r);
 	for (uint32_t k = 0; k < cnt; ++k) {
+#if MIRT_STATS
+		atomicAdd(g_statMembEntries, 1ull);
+#endif
 		const float4 lo = m[2 * k], hi = m[2 * k + 1];
 		float tn;
 		if (box_hit<MODE_EXACT>(r, e, F3(lo), F3(hi), tn)) return __float_as_uint(lo.w);
