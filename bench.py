@@ -241,6 +241,8 @@ def main():
     locals_ = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(depth)]
     images = [torch.empty(width * height * 3, dtype=torch.uint8, device="cuda") for _ in range(depth)] if (world > 1 and rank == 0) else None
     gloo = world > 1 and args.backend == "gloo"
+    # rank 0's landing area of the gather, one per stream, allocated once
+    gathered = [torch.empty((world, nbytes), dtype=torch.uint8, device="cpu" if gloo else "cuda") for _ in range(depth)] if (world > 1 and rank == 0) else None
     frame_no = [0]
 
     def step():
@@ -251,7 +253,7 @@ def main():
             scene.render_device(params, local.data_ptr(), nbytes, st.cuda_stream)
             if world > 1:
                 src = local.cpu() if gloo else local
-                got = multigpu.gather_to_root(src, world, rank, dist)
+                got = multigpu.gather_to_root(src, world, rank, dist, out=gathered[k] if gathered else None)
                 if rank == 0:
                     got = got.cuda() if gloo else got
                     scene.assemble_tiles(params, world, got.data_ptr(), nbytes, images[k].data_ptr(), st.cuda_stream)

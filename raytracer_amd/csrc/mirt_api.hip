@@ -11,7 +11,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -165,6 +168,95 @@ static __device__ __align__(256) unsigned char scratch[MIRT_NOALLOC_SCRATCH_BYTE
 #define MIRT_MAX_DEVICES 64
 static unsigned char* g_scratchPtr[MIRT_MAX_DEVICES];
 
+// Device buffer -> pageable host buffer through page-locked staging, band by band, with helper threads (see mirt_scene).
+struct CopyBack {
+	static const int MAX_BANDS = 32;
+	int device;
+	void* staging = nullptr;
+	size_t stagingBytes = 0;
+	hipEvent_t ev[MAX_BANDS];
+	int nEv = 0;
+	// one job at a time; workers sleep on the condition variable between jobs
+	std::vector<std::thread> workers;
+	std::mutex mu;
+	std::condition_variable cv, cvDone;
+	uint64_t jobNo = 0;
+	bool quit = false;
+	int busy = 0;
+	// the job
+	uint8_t* dst = nullptr;
+	size_t bytes = 0, band = 0;
+	int nBands = 0;
+	std::atomic<int> next{0};
+	std::atomic<bool> failed{false};
+
+	CopyBack(int dev, int nThreads) : device(dev) {
+		for (int i = 0; i < nThreads; ++i) workers.emplace_back([this]() { loop(); });
+	}
+	~CopyBack() {
+		{ std::lock_guard<std::mutex> lk(mu); quit = true; }
+		cv.notify_all();
+		for (auto& t : workers) t.join();
+		for (int i = 0; i < nEv; ++i) (void)hipEventDestroy(ev[i]);
+		if (staging) (void)hipHostFree(staging);
+	}
+	void drain() { // bands, whoever gets them: wait for the band's DMA, move it
+		for (;;) {
+			const int k = next.fetch_add(1);
+			if (k >= nBands) return;
+			if (hipEventSynchronize(ev[k]) != hipSuccess) { failed = true; continue; }
+			const size_t at = (size_t)k * band, n = at + band <= bytes ? band : bytes - at;
+			memcpy(dst + at, (const uint8_t*)staging + at, n);
+		}
+	}
+	void loop() {
+		(void)hipSetDevice(device);
+		uint64_t seen = 0;
+		for (;;) {
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk, [&]() { return quit || jobNo != seen; });
+				if (quit) return;
+				seen = jobNo;
+			}
+			drain();
+			{ std::lock_guard<std::mutex> lk(mu); --busy; }
+			cvDone.notify_one();
+		}
+	}
+	// false: staging or events could not be had (nothing was copied)
+	bool run(const void* dsrc, uint8_t* hdst, size_t n, hipStream_t st) {
+		if (n > stagingBytes) {
+			if (staging) (void)hipHostFree(staging);
+			staging = nullptr;
+			stagingBytes = 0;
+			if (hipHostMalloc(&staging, n, hipHostMallocDefault) != hipSuccess) { staging = nullptr; return false; }
+			stagingBytes = n;
+		}
+		static const size_t bandBytes = []() { const char* e = getenv("MIRT_COPY_BAND_MB"); const int v = e ? atoi(e) : 0; return (size_t)(v >= 1 && v <= 64 ? v : 2) << 20; }();
+		int want = (int)((n + bandBytes - 1) / bandBytes); // bands of about 2 MB: 1 MB bands cost more per copy than they gain at the end (+0.1 ms per 4K frame)
+		want = want < 1 ? 1 : (want > MAX_BANDS ? MAX_BANDS : want);
+		while (nEv < want) { if (hipEventCreateWithFlags(&ev[nEv], hipEventDisableTiming) != hipSuccess) return false; ++nEv; }
+		band = ((n + want - 1) / want + 255) & ~(size_t)255;
+		nBands = (int)((n + band - 1) / band);
+		dst = hdst;
+		bytes = n;
+		failed = false;
+		for (int k = 0; k < nBands; ++k) {
+			const size_t at = (size_t)k * band, len = at + band <= n ? band : n - at;
+			if (hipMemcpyAsync((uint8_t*)staging + at, (const uint8_t*)dsrc + at, len, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+			if (hipEventRecord(ev[k], st) != hipSuccess) return false;
+		}
+		next = 0;
+		{ std::lock_guard<std::mutex> lk(mu); busy = (int)workers.size(); ++jobNo; }
+		cv.notify_all();
+		drain(); // the calling thread moves bands too
+		{ std::unique_lock<std::mutex> lk(mu); cvDone.wait(lk, [&]() { return busy == 0; }); }
+		if (failed) return hipStreamSynchronize(st) == hipSuccess && hipMemcpy(hdst, dsrc, n, hipMemcpyDeviceToHost) == hipSuccess;
+		return true;
+	}
+};
+
 struct mirt_scene {
 	int device = 0;
 	int numCUs = 256;
@@ -184,6 +276,12 @@ struct mirt_scene {
 	uint32_t diag[8] = {0}; // builder facts: binary interior nodes, binary leaves, wide nodes with 1..4 children
 	std::vector<FrameCtx*> ctxs; // one per stream that has rendered with this scene
 	bool profiling = false;
+	// mirt_render's copy back: the frame goes to a page-locked staging buffer in bands (one DMA each, PCIe speed) and a few
+	// host threads move each band into the caller's pageable buffer while the next bands are still on their way.  HIP's own
+	// copy to pageable memory takes 1.4 ms for the 24.9 MB of a 4K frame; page-locking the caller's buffer in place
+	// (hipHostRegister) is refused on the machines this was developed on.  MIRT_COPY_THREADS=0 goes back to the plain copy.
+	CopyBack* copyBack = nullptr;
+	int copyThreads = 6;
 	bool singleLaunch = true; // frames run as one launch (k_frame) where that kernel applies; MIRT_SINGLE_LAUNCH=0: one launch per depth
 };
 
@@ -923,6 +1021,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	// Long walks (big scenes) make refilling idle lanes pay; short ones do not (see k_trace).  MIRT_REFILL_MIN overrides.
 	s->refillMin = bvhWide.size() / 16 > 500000u ? 36u : 64u;
 	if (const char* env = getenv("MIRT_SINGLE_LAUNCH")) s->singleLaunch = atoi(env) != 0;
+	if (const char* env = getenv("MIRT_COPY_THREADS")) { const int v = atoi(env); if (v >= 0 && v <= 32) s->copyThreads = v; }
 	if (const char* env = getenv("MIRT_REFILL_MIN")) { const int v = atoi(env); if (v >= 1 && v <= 64) s->refillMin = (uint32_t)v; }
 	memcpy(s->diag, bvhDiag, sizeof bvhDiag);
 	ds.bvhRoot = bvhRoot;
@@ -1073,6 +1172,8 @@ void mirt_scene_destroy(mirt_scene* s) {
 	(void)hipSetDevice(s->device);
 	// the whole device, not stream by stream: a caller's stream may have been destroyed since its last frame
 	(void)hipDeviceSynchronize();
+	delete s->copyBack;
+	s->copyBack = nullptr;
 	s->nodes.release(); s->leafs.release(); s->bvh.release(); s->memb.release(); s->tris.release(); s->triX.release(); s->triInfo.release();
 	s->spheres.release(); s->sphInfo.release(); s->materials.release(); s->lights.release(); s->hookOvf.release(); s->dbg.release();
 	for (FrameCtx* c : s->ctxs) {
@@ -1263,6 +1364,14 @@ int mirt_render(mirt_scene* s, const mirt_render_params* p, uint8_t* bgr_out, mi
 	if ((e = c->ws.out.ensure(bytes))) return e;
 	if ((e = render_async(s, p, c->ws.out.p, bytes, s->stream, !whole))) return e;
 	if (whole) {
+		if (s->copyThreads > 0 && bytes >= (4u << 20)) {
+			if (!s->copyBack) s->copyBack = new (std::nothrow) CopyBack(s->device, s->copyThreads);
+			if (s->copyBack && s->copyBack->run(c->ws.out.p, bgr_out, bytes, s->stream)) {
+				if (stats) return read_stats(s, s->stream, stats);
+				return MIRT_OK;
+			}
+			(void)hipGetLastError(); // staging not available: the plain copy below
+		}
 		HIPCHK(hipMemcpyAsync(bgr_out, c->ws.out.p, bytes, hipMemcpyDeviceToHost, s->stream));
 		HIPCHK(hipStreamSynchronize(s->stream));
 	}
@@ -1294,6 +1403,14 @@ int mirt_assemble_tiles(int device, const mirt_render_params* p, uint32_t n_rank
 	if (per_rank_bytes < (size_t)g.nSlots * 3) return fail(MIRT_E_INVALID, "per_rank_bytes %zu smaller than a rank's tile buffer %zu", per_rank_bytes, (size_t)g.nSlots * 3);
 	HIPCHK(hipSetDevice(device));
 	const uint64_t n = (uint64_t)p->width * p->height;
+	if ((tw * 3u) % 16u == 0 && (p->width * 3ull) % 16u == 0 && per_rank_bytes % 16u == 0 && ((uintptr_t)d_tiles | (uintptr_t)d_bgr) % 16u == 0) {
+		const uint64_t nTiles = (uint64_t)g.tilesX * g.tilesY, pieces = nTiles * th * (tw * 3u / 16u);
+		const int grid16 = (int)((pieces + BLOCK - 1) / BLOCK < 16384 ? (pieces + BLOCK - 1) / BLOCK : 16384);
+		hipLaunchKernelGGL(k_assemble16, dim3(grid16), dim3(BLOCK), 0, (hipStream_t)hip_stream, p->width, p->height, tw, th, g.tilesX, (uint32_t)nTiles, n_ranks,
+		                   (const uint8_t*)d_tiles, per_rank_bytes, (uint8_t*)d_bgr);
+		HIPCHK(hipGetLastError());
+		return MIRT_OK;
+	}
 	const int grid = (int)((n + BLOCK - 1) / BLOCK < 8192 ? (n + BLOCK - 1) / BLOCK : 8192);
 	hipLaunchKernelGGL(k_assemble, dim3(grid), dim3(BLOCK), 0, (hipStream_t)hip_stream, p->width, p->height, tw, th, g.tilesX, n_ranks,
 	                   (const uint8_t*)d_tiles, per_rank_bytes, (uint8_t*)d_bgr);

@@ -1475,3 +1475,26 @@ __global__ __launch_bounds__(BLOCK) void k_assemble(uint32_t width, uint32_t hei
 		bgr[3 * i + 2] = tiles[src + 2];
 	}
 }
+
+// The same in 16-byte pieces, for the usual case: a tile row (tileW * 3 bytes) and an image row (width * 3 bytes) are
+// multiples of 16 bytes and both buffers are 16-byte aligned, so every piece is aligned on both sides.  One thread moves
+// one piece; the pieces of a tile are consecutive in the gathered buffer (a tile is tileW * tileH * 3 contiguous bytes).
+// The last bytes of an edge tile's rows (image width not a multiple of the tile width) go one by one.
+__global__ __launch_bounds__(BLOCK) void k_assemble16(uint32_t width, uint32_t height, uint32_t tileW, uint32_t tileH, uint32_t tilesX, uint32_t nTiles,
+                                                     uint32_t nRanks, const uint8_t* __restrict__ tiles, size_t perRank, uint8_t* __restrict__ bgr) {
+	const uint32_t chunks = tileW * 3u / 16u;          // pieces per tile row
+	const uint32_t perTile = tileH * chunks;
+	const uint64_t n = (uint64_t)nTiles * perTile;
+	for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
+		const uint32_t k = (uint32_t)(i / perTile), r = (uint32_t)(i - (uint64_t)k * perTile);
+		const uint32_t y = r / chunks, c = r - y * chunks;
+		const uint32_t px0 = (k % tilesX) * tileW, py = (k / tilesX) * tileH + y;
+		if (py >= height) continue;
+		const uint32_t rowBytes = (px0 + tileW <= width ? tileW : width - px0) * 3u; // bytes of this tile's row that lie in the image
+		const uint32_t rank = k % nRanks, lt = k / nRanks;
+		const uint8_t* src = tiles + (size_t)rank * perRank + ((size_t)lt * tileW * tileH + (size_t)y * tileW) * 3 + (size_t)c * 16;
+		uint8_t* dst = bgr + ((size_t)py * width + px0) * 3 + (size_t)c * 16;
+		if (c * 16u + 16u <= rowBytes) *(uint4*)dst = *(const uint4*)src;
+		else for (uint32_t b = c * 16u; b < rowBytes; ++b) dst[b - c * 16u] = src[b - c * 16u];
+	}
+}

@@ -68,14 +68,16 @@ def pack_tiles_host(img, rank, world, tile_w=TILE_W, tile_h=TILE_H):
     return buf
 
 
-def gather_to_root(local, world, rank, dist, root=0):
+def gather_to_root(local, world, rank, dist, root=0, out=None):
     """One collective per frame: every rank's equally sized buffer to `root`.  `local` is a torch tensor (GPU for RCCL,
-    CPU for gloo).  Returns the [world, n] tensor on root, None elsewhere."""
+    CPU for gloo).  Returns the [world, n] tensor on root (`out` if given: a buffer allocated once per stream, not per
+    frame), None elsewhere."""
     import torch
     if world == 1:
         return local.unsqueeze(0)
     if rank == root:
-        out = torch.empty((world, local.numel()), dtype=local.dtype, device=local.device)
+        if out is None:
+            out = torch.empty((world, local.numel()), dtype=local.dtype, device=local.device)
         dist.gather(local, gather_list=list(out.unbind(0)), dst=root)
         return out
     dist.gather(local, gather_list=None, dst=root)
