@@ -166,6 +166,16 @@ typedef struct mirt_scene mirt_scene;
 int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out);
 void mirt_scene_destroy(mirt_scene* scene);
 
+/* Scene cache.  mirt_scene_create spends seconds on big scenes (membership lists, hierarchy build, record packing:
+ * 5 s for 10 M triangles) after the host has spent its own on Scene::Scene (Scene.cpp:15-224: parse, then `new
+ * Partition`).  mirt_scene_save writes the device form of an uploaded scene to a file; mirt_scene_load brings it back
+ * onto a device without the reference's loader, the tree or mirt_scene_create, ready to render the same images.
+ * user[4] are four words of the caller's own that travel with the file (e.g. image width and height; may be NULL).
+ * The file is tied to the library version that wrote it (a newer library refuses it) and carries a checksum; it is
+ * trusted otherwise, like the library itself.  No counterpart in the reference. */
+int mirt_scene_save(mirt_scene* scene, const char* path, const uint32_t user[4]);
+int mirt_scene_load(const char* path, int device, mirt_scene** out, uint32_t user_out[4]);
+
 /* Replaces the pixel loop main.cpp:137-157: fills bgr_out[3*(i*width+j)+{0,1,2}] = B,G,R for every pixel of
  * the tiles selected by params; bytes of other tiles are left untouched.  bgr_out is host memory of
  * width*height*3 bytes, top row first -- exactly what Renderer::createImage(BYTE*, std::string) takes

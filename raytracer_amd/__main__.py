@@ -1,6 +1,10 @@
 """Scene file in, PNG and report out: what the reference's createRender does for one scene (main.cpp:104-173), on the GPU.
 
-    python -m raytracer_amd scene.test [--out image.png] [--size W H] [--features 15] [--debug 6] [--device 0]
+    python -m raytracer_amd scene.test [--out image.png] [--size W H] [--features 15] [--debug 6] [--device 0] [--cache scene.mirt]
+
+With --cache the uploaded scene is written to that file after the first load, and later runs start from it: no scene
+text, no Partition build, no hierarchy build (mirt_scene_save / mirt_scene_load; the reference parses and builds every
+time, Scene.cpp:15-224).
 
 The output name defaults to the scene's `output` command, as in the reference (main.cpp:113-119).  The report lists the
 same facts as createPerformanceReport (main.cpp:314-344), with the object and light counters filled in (the reference
@@ -20,7 +24,29 @@ DEBUG_NAMES = ["DIFFUSE_INTENSITY", "SPECULAR_INTENSITY", "NORMAL_MAP", "SHADOW_
                "LIGHT_DIRECTION_MAP", "NONE"]                                                     # main.cpp:24-33
 
 
-def render_file(scene_path, out_path=None, size=None, features=_capi.F_ALL, debug=_capi.DEBUG_NONE, device=0, report=True):
+def render_cached(cache_path, out_path, size=None, features=_capi.F_ALL, debug=_capi.DEBUG_NONE, device=0):
+    """Render from a scene cache file.  Returns (image, stats, report lines)."""
+    t0 = time.perf_counter()
+    scene, user = DeviceScene.load(cache_path, device)
+    t_load = time.perf_counter() - t0
+    w, h = size or (user[0], user[1])
+    with scene as s:
+        img, st = s.render(w, h, features=features, debug=debug)
+        facts = s.query()
+    t0 = time.perf_counter()
+    write_png(out_path, img)
+    t_png = time.perf_counter() - t0
+    rays = st["primary_rays"] + st["shadow_rays"] + st["reflection_rays"]
+    lines = ["PERFORMANCE REPORT FOR " + os.path.basename(out_path), "Scene cache: %s (%d bytes on the device)" % (cache_path, facts["device_bytes"]),
+             "Resolution: %dx%d" % (w, h), "Render Time: %.3f ms on the device" % st["device_ms"],
+             "Scene from cache: %.3f s, PNG: %.3f s" % (t_load, t_png),
+             "Rays: %d primary, %d shadow, %d reflection (%.1f Mrays/s)" % (st["primary_rays"], st["shadow_rays"], st["reflection_rays"], rays / max(st["device_ms"], 1e-9) / 1e3)]
+    return img, st, lines
+
+
+def render_file(scene_path, out_path=None, size=None, features=_capi.F_ALL, debug=_capi.DEBUG_NONE, device=0, report=True, cache=None):
+    if cache and os.path.exists(cache):
+        return render_cached(cache, out_path or os.path.splitext(os.path.basename(scene_path))[0] + ".png", size, features, debug, device)
     t0 = time.perf_counter()
     flat = FlatScene.from_file(scene_path)
     t_load = time.perf_counter() - t0
@@ -30,6 +56,8 @@ def render_file(scene_path, out_path=None, size=None, features=_capi.F_ALL, debu
     t0 = time.perf_counter()
     with DeviceScene(flat, device) as s:
         t_upload = time.perf_counter() - t0
+        if cache:
+            s.save(cache, user=(flat.width, flat.height, 0, 0))
         img, st = s.render(flat.width, flat.height, features=features, debug=debug)
     t0 = time.perf_counter()
     write_png(out_path, img)
@@ -69,8 +97,9 @@ def main():
     ap.add_argument("--features", type=int, default=_capi.F_ALL)
     ap.add_argument("--debug", type=int, default=_capi.DEBUG_NONE)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--cache", help="scene cache file: written after the first load, read instead of the scene text afterwards")
     a = ap.parse_args()
-    _, _, lines = render_file(a.scene, a.out, a.size, a.features, a.debug, a.device)
+    _, _, lines = render_file(a.scene, a.out, a.size, a.features, a.debug, a.device, cache=a.cache)
     print("\n".join(lines))
 
 

@@ -86,6 +86,8 @@ def make_params(width, height, features=F_ALL, debug=DEBUG_NONE, trace_mode=TRAC
 SYMBOLS = [
     ("mirt_scene_create", C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]),
     ("mirt_scene_destroy", None, [C.c_void_p]),
+    ("mirt_scene_save", C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
+    ("mirt_scene_load", C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]),
     ("mirt_render", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]),
     ("mirt_render_device", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_size_t, C.c_void_p]),
     ("mirt_tile_buffer_bytes", C.c_size_t, [C.POINTER(RenderParams)]),

@@ -1187,6 +1187,154 @@ void mirt_scene_destroy(mirt_scene* s) {
 	delete s;
 }
 
+// ---- scene cache: the device form of a scene in a file (what mirt_scene_create spends its seconds on) ----------------------------
+// Layout: header { magic, version, sizeof(DScene), sizeof(SceneMeta), user[4], payload checksum }, the DScene record
+// (pointers meaningless), SceneMeta, then for each of the eleven device arrays a 64-bit byte count and the bytes.
+namespace {
+const char SCENE_MAGIC[8] = {'M', 'I', 'R', 'T', 'S', 'C', 'N', '1'};
+const uint32_t SCENE_VERSION = 2;
+struct SceneHeader {
+	char magic[8];
+	uint32_t version, dsceneBytes, metaBytes, pad;
+	uint32_t user[4];
+	uint64_t checksum; // FNV-1a over everything after the header
+};
+struct SceneMeta {
+	uint32_t nested, bvhDepth, deepBvh, nLights;
+	int32_t maxDepth;
+	uint32_t wideDepth, refillMin, ovfLevels;
+	uint32_t diag[8];
+};
+inline uint64_t fnv1a(uint64_t h, const void* p, size_t n) {
+	// eight bytes at a time (a byte-wise pass over the 3.5 GB of a 10 M-triangle scene would take seconds)
+	const uint8_t* b = (const uint8_t*)p;
+	size_t i = 0;
+	for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, b + i, 8); h = (h ^ w) * 0x100000001b3ull; }
+	for (; i < n; ++i) h = (h ^ b[i]) * 0x100000001b3ull;
+	return h;
+}
+DevBuf* scene_buffers(mirt_scene* s, int k) {
+	DevBuf* const all[11] = {&s->nodes, &s->leafs, &s->bvh, &s->memb, &s->tris, &s->triX, &s->triInfo, &s->spheres, &s->sphInfo, &s->materials, &s->lights};
+	return all[k];
+}
+void scene_bind(mirt_scene* s) {
+	DScene& ds = s->ds;
+	ds.nodes = (const float4*)s->nodes.p;
+	ds.leafs = (const uint32_t*)s->leafs.p;
+	ds.bvh = (const float4*)s->bvh.p;
+	ds.memb = (const float4*)s->memb.p;
+	ds.tris = (const float4*)s->tris.p;
+	ds.triX = (const float4*)s->triX.p;
+	ds.triInfo = (const uint4*)s->triInfo.p;
+	ds.spheres = (const float4*)s->spheres.p;
+	ds.sphInfo = (const uint4*)s->sphInfo.p;
+	ds.materials = (const float4*)s->materials.p;
+	ds.lights = (const float4*)s->lights.p;
+	ds.dbg = (unsigned long long*)s->dbg.p;
+}
+}  // namespace
+
+int mirt_scene_save(mirt_scene* s, const char* path, const uint32_t user[4]) {
+	if (!s || !path) return fail(MIRT_E_INVALID, "NULL argument");
+	HIPCHK(hipSetDevice(s->device));
+	HIPCHK(hipDeviceSynchronize());
+	FILE* f = fopen(path, "wb");
+	if (!f) return fail(MIRT_E_INVALID, "cannot create %s", path);
+	SceneHeader h;
+	memset(&h, 0, sizeof h);
+	memcpy(h.magic, SCENE_MAGIC, 8);
+	h.version = SCENE_VERSION;
+	h.dsceneBytes = sizeof(DScene);
+	h.metaBytes = sizeof(SceneMeta);
+	if (user) memcpy(h.user, user, sizeof h.user);
+	SceneMeta m;
+	memset(&m, 0, sizeof m);
+	m.nested = s->nested; m.bvhDepth = s->bvhDepth; m.deepBvh = s->deepBvh; m.nLights = s->nLights; m.maxDepth = s->maxDepth;
+	m.wideDepth = s->wideDepth; m.refillMin = s->refillMin; m.ovfLevels = s->ovfLevels;
+	memcpy(m.diag, s->diag, sizeof m.diag);
+	bool ok = fwrite(&h, sizeof h, 1, f) == 1;
+	uint64_t sum = 0xcbf29ce484222325ull;
+	auto put = [&](const void* p, size_t n) { sum = fnv1a(sum, p, n); ok = ok && (n == 0 || fwrite(p, n, 1, f) == 1); };
+	put(&s->ds, sizeof s->ds);
+	put(&m, sizeof m);
+	std::vector<uint8_t> tmp;
+	for (int k = 0; k < 11 && ok; ++k) {
+		DevBuf* b = scene_buffers(s, k);
+		const uint64_t n = b->bytes;
+		put(&n, 8);
+		tmp.resize(n);
+		if (n && hipMemcpy(tmp.data(), b->p, n, hipMemcpyDeviceToHost) != hipSuccess) { fclose(f); return fail(MIRT_E_DEVICE, "mirt_scene_save: copy from the device failed"); }
+		put(tmp.data(), n);
+	}
+	h.checksum = sum;
+	ok = ok && fseek(f, 0, SEEK_SET) == 0 && fwrite(&h, sizeof h, 1, f) == 1;
+	ok = (fclose(f) == 0) && ok;
+	if (!ok) return fail(MIRT_E_INVALID, "writing %s failed", path);
+	return MIRT_OK;
+}
+
+int mirt_scene_load(const char* path, int device, mirt_scene** out, uint32_t user_out[4]) {
+	if (!path || !out) return fail(MIRT_E_INVALID, "NULL argument");
+	*out = nullptr;
+	FILE* f = fopen(path, "rb");
+	if (!f) return fail(MIRT_E_INVALID, "cannot open %s", path);
+	SceneHeader h;
+	if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, SCENE_MAGIC, 8) != 0) { fclose(f); return fail(MIRT_E_INVALID, "%s is not a scene cache file", path); }
+	if (h.version != SCENE_VERSION || h.dsceneBytes != sizeof(DScene) || h.metaBytes != sizeof(SceneMeta)) {
+		fclose(f);
+		return fail(MIRT_E_INVALID, "%s was written by another version of the library (format %u, this library reads %u): build the scene again", path, h.version, SCENE_VERSION);
+	}
+	hipError_t he = hipSetDevice(device);
+	hipDeviceProp_t prop;
+	if (he == hipSuccess) he = hipGetDeviceProperties(&prop, device);
+	if (he != hipSuccess) { fclose(f); return fail(MIRT_E_DEVICE, "device %d: %s", device, hipGetErrorString(he)); }
+	int e = scratch_init(device);
+	if (e) { fclose(f); return e; }
+	mirt_scene* s = new (std::nothrow) mirt_scene();
+	if (!s) { fclose(f); return fail(MIRT_E_NOMEM, "out of host memory"); }
+	s->device = device;
+	s->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	SceneMeta m;
+	uint64_t sum = 0xcbf29ce484222325ull;
+	bool ok = fread(&s->ds, sizeof s->ds, 1, f) == 1 && fread(&m, sizeof m, 1, f) == 1;
+	if (ok) { sum = fnv1a(sum, &s->ds, sizeof s->ds); sum = fnv1a(sum, &m, sizeof m); }
+	const char* why = "truncated file";
+	std::vector<uint8_t> tmp;
+	static const uint32_t recordBytes[11] = {64, 4, 64, 32, 64, 32, 16, 144, 16, 64, 32};
+	for (int k = 0; k < 11 && ok; ++k) {
+		uint64_t n = 0;
+		ok = fread(&n, 8, 1, f) == 1;
+		if (!ok) break;
+		sum = fnv1a(sum, &n, 8);
+		if (n > (1ull << 40) || (n % recordBytes[k] != 0 && n != 16)) { ok = false; why = "array size not a whole number of records"; break; }
+		try { tmp.resize(n); } catch (...) { ok = false; why = "out of host memory"; break; }
+		if (n && fread(tmp.data(), n, 1, f) != 1) { ok = false; break; }
+		sum = fnv1a(sum, tmp.data(), n);
+		if (upload(*scene_buffers(s, k), tmp.data(), n)) { ok = false; why = "device allocation or copy failed"; break; }
+	}
+	fclose(f);
+	if (ok && sum != h.checksum) { ok = false; why = "checksum mismatch (file damaged)"; }
+	if (ok && (m.maxDepth > MIRT_MAX_DEPTH_LIMIT || m.nLights != s->ds.nLights || s->lights.bytes < (size_t)m.nLights * 32)) { ok = false; why = "inconsistent header"; }
+	if (ok && (s->dbg.ensure(32 * 8) || hipMemset(s->dbg.p, 0, 32 * 8) != hipSuccess)) { ok = false; why = "device allocation failed"; }
+	if (!ok) {
+		mirt_scene_destroy(s);
+		return fail(MIRT_E_INVALID, "%s: %s", path, why);
+	}
+	s->nested = m.nested != 0; s->bvhDepth = m.bvhDepth; s->deepBvh = m.deepBvh != 0; s->nLights = m.nLights; s->maxDepth = m.maxDepth;
+	s->wideDepth = m.wideDepth; s->refillMin = m.refillMin; s->ovfLevels = m.ovfLevels;
+	memcpy(s->diag, m.diag, sizeof m.diag);
+	s->ovfStride = (uint32_t)s->numCUs * GRID_BLOCKS_PER_CU * BLOCK;
+	if (const char* env = getenv("MIRT_SINGLE_LAUNCH")) s->singleLaunch = atoi(env) != 0;
+	if (const char* env = getenv("MIRT_COPY_THREADS")) { const int v = atoi(env); if (v >= 0 && v <= 32) s->copyThreads = v; }
+	if (const char* env = getenv("MIRT_REFILL_MIN")) { const int v = atoi(env); if (v >= 1 && v <= 64) s->refillMin = (uint32_t)v; }
+	if (s->deepBvh && s->hookOvf.ensure((size_t)s->ovfLevels * s->ovfStride * 4)) { mirt_scene_destroy(s); return MIRT_E_NOMEM; }
+	if (hipStreamCreate(&s->stream) != hipSuccess) { mirt_scene_destroy(s); return fail(MIRT_E_DEVICE, "hipStreamCreate failed"); }
+	scene_bind(s);
+	if (user_out) memcpy(user_out, h.user, sizeof h.user);
+	*out = s;
+	return MIRT_OK;
+}
+
 int mirt_release_stream(mirt_scene* s, void* hip_stream) {
 	if (!s) return fail(MIRT_E_INVALID, "scene handle is NULL");
 	HIPCHK(hipSetDevice(s->device));

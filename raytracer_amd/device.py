@@ -2,6 +2,7 @@
 Renderer::createImage takes (reference RayTracer/Renderer.h:9) comes out.  Thin ctypes calls into libmirt.so;
 there is no CPU fallback -- a missing library or device raises."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -31,6 +32,24 @@ class DeviceScene:
         h = C.c_void_p()
         _check(self.lib, self.lib.mirt_scene_create(C.byref(d), device, C.byref(h)))
         self.h = h
+
+    # ---- scene cache (mirt_scene_save / mirt_scene_load) -----------------------------------------------------------------------
+    def save(self, path, user=(0, 0, 0, 0)):
+        u = (C.c_uint32 * 4)(*user)
+        _check(self.lib, self.lib.mirt_scene_save(self.h, os.fsencode(path), u))
+
+    @classmethod
+    def load(cls, path, device=0, lib=None):
+        """A scene from its cache file: no scene text, no tree, no mirt_scene_create.  Returns (scene, user words)."""
+        self = cls.__new__(cls)
+        self.lib = lib or _capi.load_library()
+        self.flat = None
+        self.device = device
+        h = C.c_void_p()
+        u = (C.c_uint32 * 4)()
+        _check(self.lib, self.lib.mirt_scene_load(os.fsencode(path), device, C.byref(h), u))
+        self.h = h
+        return self, tuple(int(x) for x in u)
 
     def close(self):
         if getattr(self, "h", None):

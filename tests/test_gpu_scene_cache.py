@@ -1,0 +1,70 @@
+"""GPU: mirt_scene_save / mirt_scene_load -- the device form of a scene in a file.  A scene that comes back from its cache
+renders the reference's images byte for byte without the scene text, the tree or mirt_scene_create; a damaged or foreign
+file is refused with a message."""
+import numpy as np
+import pytest
+
+from conftest import bits
+from raytracer_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["scene5", "scene6", "scene7"])
+def test_scene_from_cache_renders_the_same_images(name, flat_scenes, goldens, tmp_path):
+    from raytracer_amd.device import DeviceScene
+    g = goldens(name)
+    w, h = int(g["width"]), int(g["height"])
+    path = str(tmp_path / (name + ".mirt"))
+    with DeviceScene(flat_scenes(name), 0) as s:
+        facts = s.query()
+        s.save(path, user=(w, h, 7, 9))
+    cached, user = DeviceScene.load(path, 0)
+    with cached as s:
+        assert user == (w, h, 7, 9)
+        assert s.query() == facts
+        for features in (15, 7, 11, 3):
+            img, st = s.render(w, h, features=features)
+            assert np.array_equal(img, g["bgr_f%d" % features])
+            assert [st["primary_rays"], st["shadow_rays"], st["reflection_rays"]] == g["rays_f%d" % features].tolist()
+        img, _ = s.render(w, h, debug=_capi.DEBUG_SHADOW_MAP)
+        assert np.array_equal(img, g["bgr_debug%d" % _capi.DEBUG_SHADOW_MAP])
+        ids, dist = s.trace_primary_ids(w, h)
+        assert np.array_equal(ids, g["prim_id"]) and np.array_equal(bits(dist), bits(g["dist"]))
+        ids, dist = s.trace_primary_ids(w, h, trace_mode=_capi.TRACE_REFWALK)   # the reference's own tree travels too
+        assert np.array_equal(ids, g["prim_id"]) and np.array_equal(bits(dist), bits(g["dist"]))
+
+
+def test_damaged_and_foreign_files_are_refused(flat_scenes, tmp_path):
+    from raytracer_amd.device import DeviceScene, MirtError
+    path = tmp_path / "scene6.mirt"
+    with DeviceScene(flat_scenes("scene6"), 0) as s:
+        s.save(str(path))
+    raw = bytearray(path.read_bytes())
+    bad = tmp_path / "flipped.mirt"
+    flipped = bytearray(raw)
+    flipped[len(raw) // 2] ^= 0x10
+    bad.write_bytes(flipped)
+    with pytest.raises(MirtError, match="checksum"):
+        DeviceScene.load(str(bad), 0)
+    bad.write_bytes(raw[:len(raw) // 3])
+    with pytest.raises(MirtError, match="truncated"):
+        DeviceScene.load(str(bad), 0)
+    bad.write_bytes(b"not a scene at all, just text that is longer than the header of a cache file would be" * 2)
+    with pytest.raises(MirtError, match="not a scene cache"):
+        DeviceScene.load(str(bad), 0)
+    with pytest.raises(MirtError, match="cannot open"):
+        DeviceScene.load(str(tmp_path / "missing.mirt"), 0)
+
+
+def test_command_line_starts_from_the_cache_the_second_time(tmp_path, goldens, monkeypatch):
+    import os
+    from raytracer_amd.__main__ import render_file
+    monkeypatch.chdir(tmp_path)
+    scene = os.path.join(os.path.dirname(__file__), "golden", "scenes", "scene6.test")
+    cache = str(tmp_path / "cornell.mirt")
+    a, _, _ = render_file(scene, out_path=str(tmp_path / "a.png"), cache=cache)
+    assert os.path.exists(cache)
+    b, _, lines = render_file("/nonexistent/scene6.test", out_path=str(tmp_path / "b.png"), cache=cache)  # the text is not read again
+    assert np.array_equal(a, b) and np.array_equal(a, goldens("c1_cornell")["bgr"])
+    assert any("Scene cache" in l for l in lines)
