@@ -888,6 +888,13 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	uint32_t bvhRoot = BVH_DONE, bvhWideDepth = 0, bvhMaxStack = 0;
 	uint32_t bvhDiag[8] = {0};
 	float bvhMin[3] = {0, 0, 0}, bvhMax[3] = {-1, -1, -1};
+	// (a serial recursion over the binary hierarchy: it runs on a thread of its own beside the packing of the reference
+	// tree and of the primitive records below, which need nothing from it; joined before its results are used)
+	struct Joiner {
+		std::thread t;
+		~Joiner() { if (t.joinable()) t.join(); }
+	} collapse;
+	collapse.t = std::thread([&]() {
 	if (!bb.nodes.empty()) {
 		struct Emit {
 			const BvhBuilder& bb;
@@ -972,8 +979,8 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		memcpy(bvhMin, bb.nodes[0].lo, 12);
 		memcpy(bvhMax, bb.nodes[0].hi, 12);
 	}
+	});
 
-	phase("hierarchy collapse + pack");
 	// ---- the reference tree as it is (MODE_REFWALK) ------------------------------------------------------------------------
 	Packer pk;
 	pk.d = d;
@@ -1017,6 +1024,8 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		}
 	}
 	s->wideDepth = pk.maxDepth;
+	collapse.t.join();
+	phase("reference tree pack (hierarchy collapse beside it)");
 	s->bvhDepth = bvhWideDepth;
 	// Long walks (big scenes) make refilling idle lanes pay; short ones do not (see k_trace).  MIRT_REFILL_MIN overrides.
 	s->refillMin = bvhWide.size() / 16 > 500000u ? 36u : 64u;
@@ -1120,7 +1129,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	s->nLights = d->n_lights;
 	s->maxDepth = d->max_depth;
 
-	phase("reference tree pack + records");
+	phase("primitive records");
 	e = upload(s->nodes, pk.wide.data(), pk.wide.size() * 4);
 	if (!e) e = upload(s->leafs, pk.stream.data(), pk.stream.size() * 4);
 	if (!e) e = upload(s->bvh, bvhWide.data(), bvhWide.size() * 4);

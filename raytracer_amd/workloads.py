@@ -14,7 +14,7 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SCENE_DIR = os.path.join(os.path.dirname(HERE), "tests", "golden", "scenes")  # the reference's scene files (data)
+SCENE_DIR = os.path.join(HERE, "data", "scenes")  # the reference's scene files (input data, copied unchanged)
 
 
 # Seed of the per-instance rotation angles of dragon_grid().  With 20251111 and 20251112 the 10 x 10 grid contains two

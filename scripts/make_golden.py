@@ -4,7 +4,7 @@
 Everything written here is DATA produced by running the reference's own compiled classes
 (oracle/_ref/libref_oracle.so, built by `make -C oracle ref` from the sources under /root/reference):
 
-  tests/golden/scenes/<name>.test   the reference's scene files (input data, copied unchanged)
+  raytracer_amd/data/scenes/<name>.test   the reference's scene files (input data, copied unchanged)
   tests/golden/<name>.flat.npz      the flattened Scene (Partition tree, primitives, materials, lights, camera)
   tests/golden/<name>.golden.npz    expected outputs at 160x120: nearest-hit id / distance / normal of every
                                     primary ray, the B,G,R image for every feature combination the reference's
@@ -79,12 +79,13 @@ def secondary_rays(fs_ids, o, d, dist, nrm, lights, rng, n=4000):
 
 def main():
     build(ref=True)
-    os.makedirs(os.path.join(OUT, "scenes"), exist_ok=True)
+    scene_dir = os.path.join(ROOT, "raytracer_amd", "data", "scenes")  # input data of the package (workloads.py) and of the tests
+    os.makedirs(scene_dir, exist_ok=True)
     rng = np.random.default_rng(20251111)
     kat = {}
     for name, rel in SCENES:
         src = os.path.join(REF, rel)
-        shutil.copyfile(src, os.path.join(OUT, "scenes", name + ".test"))
+        shutil.copyfile(src, os.path.join(scene_dir, name + ".test"))
         small = with_size(src, W, H)
         ref = RefOracle(small)
         fs = ref.flatten()

@@ -112,7 +112,7 @@ def test_scene_file_to_png_end_to_end(tmp_path, goldens, monkeypatch):
     from PIL import Image
     from raytracer_amd.__main__ import render_file
     monkeypatch.chdir(tmp_path)
-    scene = os.path.join(os.path.dirname(__file__), "golden", "scenes", "scene6.test")
+    scene = os.path.join(os.path.dirname(os.path.dirname(__file__)), "raytracer_amd", "data", "scenes", "scene6.test")
     img, st, lines = render_file(scene, out_path=str(tmp_path / "cornell.png"))
     g = goldens("c1_cornell")
     assert np.array_equal(img, g["bgr"])

@@ -61,7 +61,7 @@ def test_command_line_starts_from_the_cache_the_second_time(tmp_path, goldens, m
     import os
     from raytracer_amd.__main__ import render_file
     monkeypatch.chdir(tmp_path)
-    scene = os.path.join(os.path.dirname(__file__), "golden", "scenes", "scene6.test")
+    scene = os.path.join(os.path.dirname(os.path.dirname(__file__)), "raytracer_amd", "data", "scenes", "scene6.test")
     cache = str(tmp_path / "cornell.mirt")
     a, _, _ = render_file(scene, out_path=str(tmp_path / "a.png"), cache=cache)
     assert os.path.exists(cache)

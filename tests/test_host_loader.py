@@ -1,7 +1,7 @@
 """The library's own scene loader and Partition build (include/mirt_host.h) against the reference's.
 
 The expected arrays (tests/golden/*.flat.npz) were flattened from the reference's own Scene / Partition objects
-(scripts/make_golden.py); the inputs are the reference's own scene files (tests/golden/scenes).  Everything that crosses
+(scripts/make_golden.py); the inputs are the reference's own scene files (raytracer_amd/data/scenes).  Everything that crosses
 the C ABI must be identical bit for bit: boxes, children, leaf contents and order, world-space vertices, sphere
 matrices and their inverses, materials, lights, camera.  CPU only."""
 import os
@@ -26,7 +26,7 @@ def _same(a, b):
 @pytest.mark.parametrize("name", SCENES)
 def test_loader_reproduces_the_reference_flattening(name):
     ref = FlatScene.load(os.path.join(HERE, "golden", name + ".flat.npz"))
-    mine = FlatScene.from_file(os.path.join(HERE, "golden", "scenes", name + ".test"))
+    mine = FlatScene.from_file(os.path.join(os.path.dirname(HERE), "raytracer_amd", "data", "scenes", name + ".test"))
     _same(ref, mine)
     assert mine.width > 0 and mine.height > 0
 

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(REF_LIB), reason="reference b
 
 
 def _scene_file(name, w, h, tmp_path):
-    lines = open(os.path.join(GOLDEN, "scenes", name + ".test")).read().split("\n")
+    lines = open(os.path.join(os.path.dirname(os.path.dirname(GOLDEN)), "raytracer_amd", "data", "scenes", name + ".test")).read().split("\n")
     lines = ["size %d %d" % (w, h) if ln.strip().startswith("size ") else ln for ln in lines]
     p = tmp_path / (name + ".test")
     p.write_text("\n".join(lines))
