@@ -129,7 +129,8 @@ typedef struct mirt_scene_desc {
  *   EXACT:   primitives are enumerated through the library's own hierarchy over the primitives; a candidate counts only
  *            if one of the Partition leaves that hold it passes AABB::intersect (AABB.cpp:53-72, evaluated exactly).
  *            Same result as Partition::intersect (Partition.cpp:35-53) including its tie-breaks.
- *   FAST:    as EXACT without the leaf-box check: differs only for a hit the reference's tree would not have reached.
+ *   FAST:    as EXACT without the leaf-box check: differs only for a hit the reference's tree would not have reached;
+ *            also ends a path at a material whose specular weight is zero instead of tracing the weightless reflection.
  *   REFWALK: walks the Partition tree that was handed over, box by box (cross-check and fallback; slow). */
 #define MIRT_TRACE_EXACT 0u
 #define MIRT_TRACE_FAST 1u
@@ -149,8 +150,11 @@ typedef struct mirt_render_params {
 
 /* Ray counts follow the reference's control flow: primary = pixels; shadow = one per light per hit at every
  * depth (main.cpp:208-223); reflection = one per hit at depth d < maxDepth when REFLECTIONS is on (main.cpp:177,190).
- * *_traced are the rays the device really traced (a reflection ray whose weight mat.specular is 0 in all
- * channels, and shadow rays whose contribution is multiplied by zero, may be skipped). */
+ * *_traced are the rays the device really walked: a shadow query whose light term is multiplied by exact zeros is
+ * answered without a walk in every mode (provably the same sum); a reflection ray whose weight mat.specular is zero in
+ * all channels is left out by MIRT_TRACE_FAST only -- the reference traces it (main.cpp:190) and MIRT_TRACE_EXACT does
+ * too, because 0 x (a colour that came back as inf or NaN) is not 0.  (What lies behind a path MIRT_TRACE_FAST ended is
+ * then unknown: in that mode shadow_rays and reflection_rays count the paths as far as they were followed.) */
 typedef struct mirt_stats {
 	uint64_t primary_rays, shadow_rays, reflection_rays;
 	uint64_t shadow_rays_traced, reflection_rays_traced;

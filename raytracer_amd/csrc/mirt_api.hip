@@ -721,7 +721,8 @@ int read_stats(mirt_scene* s, hipStream_t st, mirt_stats* out) {
 		out->primary_hits = cnt[CTR_F_HITS_PRIMARY];
 		out->shadow_rays = hits * s->nLights;
 		out->shadow_rays_traced = cnt[CTR_F_SHADOW_TRACED];
-		out->reflection_rays = out->reflection_rays_traced = refl;
+		out->reflection_rays = refl;
+		out->reflection_rays_traced = refl - cnt[CTR_F_REFL_SKIPPED];
 		float ms1 = 0.0f;
 		HIPCHK(hipEventElapsedTime(&ms1, c->ev0, c->ev1));
 		out->device_ms = ms1;

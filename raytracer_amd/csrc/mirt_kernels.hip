@@ -1172,6 +1172,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_FRAM
 	uint32_t pcur = wave % CTR_F_NCUR, pcurTried = 0;
 	uint32_t nShadowTraced = 0;   // per wave
 	uint32_t nHit0 = 0, nHitAll = 0, nHitLast = 0; // per wave
+	uint32_t nReflSkipped = 0;    // per lane (MIRT_TRACE_FAST only)
 #if MIRT_STATS || MIRT_TIMELINE
 	// timeline of the launch in ticks of the constant 100 MHz clock: S.dbg[16..] = first start (stored as ~t for atomicMax),
 	// last end, first and last time a wave found the slots exhausted, summed wave lifetimes, summed time after exhaustion, waves
@@ -1279,7 +1280,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_FRAM
 			}
 		}
 		else if (inBatch) { // ROUND_REFLECT: a path goes on while depth + 1 <= maxDepth (main.cpp:177,189-190)
-			if (has && depth < last) {
+			bool spawn = has && depth < last;
+			if (MODE == MODE_FAST && spawn) {
+				// The reference traces the reflection ray even when its weight mat.specular is zero in all channels
+				// (main.cpp:190), and so does MIRT_TRACE_EXACT: 0 x (what comes back) is not 0 when an inf or a NaN comes back.
+				// MIRT_TRACE_FAST leaves that case aside and ends the path here.
+				const float4 sp = S.materials[(size_t)__float_as_uint(F.litL[(size_t)depth * F.nSlots + slot].w) * 4 + 1];
+				if (sp.x == 0.0f && sp.y == 0.0f && sp.z == 0.0f) { spawn = false; ++nReflSkipped; }
+			}
+			if (spawn) {
 				const float4 ho = F.hitO[slot], hd = F.hitD[slot], hn = F.hitN[slot];
 				const f3 pd = F3(hd), N = F3(hn);
 				const f3 P = F3(ho) + normalize3(pd) * hd.w;
@@ -1400,6 +1409,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_FRAM
 	}
 #endif
 	// statistics: a few atomics per wave
+	if (MODE == MODE_FAST) {
+		for (int off = 32; off > 0; off >>= 1) nReflSkipped += __shfl_down(nReflSkipped, off);
+		if (lane == 0 && nReflSkipped) atomicAdd(F.counters + CTR_F_REFL_SKIPPED, nReflSkipped);
+	}
 	if (lane == 0) {
 		if (nShadowTraced) atomicAdd(F.counters + CTR_F_SHADOW_TRACED, nShadowTraced);
 		if (nHit0) atomicAdd(F.counters + CTR_F_HITS_PRIMARY, nHit0);

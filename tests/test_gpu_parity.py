@@ -251,3 +251,16 @@ def test_packed_tiles_and_device_assembly(world, size, dev_scenes):
     assert np.array_equal(multigpu.assemble_host(list(bufs), w, h, world), want)
     hip.free(gathered)
     hip.free(image)
+
+
+def test_fast_mode_does_not_trace_weightless_reflections(dev_scenes, goldens):
+    """scene6 (Cornell) has materials without a specular part: MIRT_TRACE_FAST ends their paths instead of tracing the
+    reflection ray the reference traces (main.cpp:190); the reference's counts stay, the image stays, fewer rays are walked."""
+    g = goldens("scene6")
+    w, h = int(g["width"]), int(g["height"])
+    s = dev_scenes("scene6")
+    _, exact = s.render(w, h)
+    img, fast = s.render(w, h, trace_mode=_capi.TRACE_FAST)
+    assert exact["reflection_rays_traced"] == exact["reflection_rays"] == int(g["rays_f15"][2])
+    assert fast["reflection_rays_traced"] < fast["reflection_rays"]
+    assert (np.abs(img.astype(int) - g["bgr_f15"].astype(int)).max(axis=2) <= 1).mean() >= 0.999
