@@ -75,7 +75,7 @@ def cpu_baseline_and_visits(flat, scene_text, width, height, row_step, use_refer
         n = rs["primary"] + rs["shadow"] + rs["reflection"]
         assert [rs["primary"], rs["shadow"], rs["reflection"]] == rays, "reference and restatement disagree on ray counts"
         base = {"value": n / rs["seconds"] / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference",
-                "sample": sample + "; reference classes compiled unmodified (g++ -O2), pixel loop only, shading driver of main.cpp restated"}
+                "sample": sample + "; reference classes and the shading functions of main.cpp compiled unmodified (g++ -O2), pixel loop only"}
         # the reference has no threads; what all host cores could do: P processes, each with the reference's own scene
         # and its own rows (every 4th row of the image, dealt round-robin), rays summed over the slowest worker's loop time
         try:
