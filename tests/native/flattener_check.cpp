@@ -1,8 +1,8 @@
-// Test harness (CPU): compiles the MirtFlattener of INTEGRATION.md -- extracted from the document into
+// Test harness (CPU): compiles the MirtFlattener of the integration guide -- extracted from the guide into
 // mirt_flattener_snippet.inc by tests/test_integration_snippet.py -- against the reference's own headers and compiled
 // classes, fills its arrays from a scene file loaded by the reference's Scene, and compares them byte for byte with arrays
 // handed in by the caller (the oracle harness's flattening of the same file).  Private members are reached the way the
-// document says: the access keywords are redefined in this translation unit only.
+// guide says: the access keywords are redefined in this translation unit only.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>

@@ -1,5 +1,5 @@
 """CPU, development container only (needs /root/reference and the reference build under oracle/_ref): the MirtFlattener
-that INTEGRATION.md tells a maintainer to add is compiled AS IT STANDS IN THE DOCUMENT against the reference's headers and
+that the integration guide at the repository root tells a maintainer to add is compiled AS IT STANDS IN THE GUIDE against the reference's headers and
 classes, and the arrays it fills are held equal, byte for byte, to the oracle harness's flattening of the same scene."""
 import ctypes as C
 import os
