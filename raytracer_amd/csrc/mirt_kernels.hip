@@ -770,6 +770,9 @@ __device__ __forceinline__ void walk_wave(const DScene& S, Walker<MODE, OVF>& w,
 		const bool wantNode = c >= 0, wantLeaf = c < -1;
 		const uint32_t nNode = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(wantNode)), nLeaf = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(wantLeaf));
 		if (nNode + nLeaf == 0u || (EARLY && 64u - (nNode + nLeaf) >= stopIdle)) break;
+		// (Measured and dropped: letting the smaller group take its step in the same iteration whenever it has at least k
+		// lanes -- nobody waits, but both steps are then issued for part of the wave each: Stanford dragon -5 % for k = 1 and
+		// 12, -4 % for 24, -3 % for 40.)
 		if (nNode * MIRT_NODE_WEIGHT >= nLeaf * MIRT_LEAF_WEIGHT) {
 #if MIRT_STATS
 			if (wantNode) STAT_WAVE(S, 8 + ((nNode + nLeaf - 1u) >> 3)); // histogram of node steps by walking lanes (at nodes or leaves), 8 per bucket
