@@ -637,16 +637,17 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 		if (!single) HIPCHK(hipMemsetAsync(F.pathDepth, 0, n, st));
 	}
 	if (single) {
-		const int grid = s->numCUs * (MIRT_FRAME_WAVES < GRID_BLOCKS_PER_CU ? MIRT_FRAME_WAVES : GRID_BLOCKS_PER_CU); // every block resident at once
+		static const int gw = []() { const char* e = getenv("MIRT_FRAME_GRID"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= MIRT_FRAME_WAVES ? v : MIRT_FRAME_WAVES; }();
+		const int grid = s->numCUs * (gw < GRID_BLOCKS_PER_CU ? gw : GRID_BLOCKS_PER_CU) * (BLOCK / FRAME_BLOCK); // every block resident at once
 		if (c) c->nLaunches = 0;
 		mark(s, c, st, -1);
 		if (effective_mode(s, p->trace_mode) == MODE_FAST) {
-			if (s->deepBvh) hipLaunchKernelGGL((k_frame<MODE_FAST, true>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, (uint8_t*)d_out);
-			else hipLaunchKernelGGL((k_frame<MODE_FAST, false>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, (uint8_t*)d_out);
+			if (s->deepBvh) hipLaunchKernelGGL((k_frame<MODE_FAST, true>), dim3(grid), dim3(FRAME_BLOCK), 0, st, s->ds, F, (uint8_t*)d_out);
+			else hipLaunchKernelGGL((k_frame<MODE_FAST, false>), dim3(grid), dim3(FRAME_BLOCK), 0, st, s->ds, F, (uint8_t*)d_out);
 		}
 		else {
-			if (s->deepBvh) hipLaunchKernelGGL((k_frame<MODE_EXACT, true>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, (uint8_t*)d_out);
-			else hipLaunchKernelGGL((k_frame<MODE_EXACT, false>), dim3(grid), dim3(BLOCK), 0, st, s->ds, F, (uint8_t*)d_out);
+			if (s->deepBvh) hipLaunchKernelGGL((k_frame<MODE_EXACT, true>), dim3(grid), dim3(FRAME_BLOCK), 0, st, s->ds, F, (uint8_t*)d_out);
+			else hipLaunchKernelGGL((k_frame<MODE_EXACT, false>), dim3(grid), dim3(FRAME_BLOCK), 0, st, s->ds, F, (uint8_t*)d_out);
 		}
 		mark(s, c, st, MIRT_K_FRAME);
 		HIPCHK(hipGetLastError());

@@ -405,12 +405,17 @@ __device__ __forceinline__ uint32_t membership(const DScene& S, const RayCtx& r,
 #ifndef MIRT_FRAME_WAVES
 #define MIRT_FRAME_WAVES 7
 #endif
+// threads of a k_frame block: its waves share nothing, so a block is ONE wave -- a block's place on the CU is free for the
+// next frame's block as soon as that wave is done, not when the slowest of four is
+#ifndef FRAME_BLOCK
+#define FRAME_BLOCK 64
+#endif
 
 // Traversal stack: STACK_LDS entries per lane in LDS ([entry][lane]: conflict-free, no address arithmetic beyond a
 // shift).  Hierarchies deeper than that (OVF = true, chosen by the host from the built depth) keep the deeper entries in
 // a global array; the two cases are separate instantiations so that the common one contains LDS instructions only
 // (a merged pointer would turn every pop into a flat_load).
-template <bool OVF, int NLDS = STACK_LDS>
+template <bool OVF, int NLDS = STACK_LDS, int STRIDE = BLOCK>
 struct LdsStack {
 	uint32_t* lds;   // this thread's column
 	uint32_t* ovf;   // [level][global thread], this thread's column
@@ -422,14 +427,14 @@ struct LdsStack {
 		atomicAdd(g_statPush, 1ull);
 		if (OVF && sp >= NLDS) atomicAdd(g_statPush + 1, 1ull);
 #endif
-		if (!OVF || sp < NLDS) lds[sp * BLOCK] = v;
+		if (!OVF || sp < NLDS) lds[sp * STRIDE] = v;
 		else {
 			uint32_t* p = ovf + (size_t)(sp - NLDS) * ovfStride;
 			asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
 		}
 	}
 	__device__ __forceinline__ uint32_t pop(int sp) {
-		if (!OVF || sp < NLDS) return lds[sp * BLOCK];
+		if (!OVF || sp < NLDS) return lds[sp * STRIDE];
 		uint32_t v;
 		const uint32_t* p = ovf + (size_t)(sp - NLDS) * ovfStride;
 		asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
@@ -1147,12 +1152,12 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DFrame F, uint8_t* __restrict
 #define FRAME_EMPTY 0xffffffffu
 
 template <int MODE, bool OVF>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_FRAME_WAVES))) void k_frame(DScene S, DFrame F, uint8_t* __restrict__ out) {
-	__shared__ uint32_t s_stack[STACK_LDS * BLOCK];
-	__shared__ uint32_t s_list[BLOCK / WAVE][128];
-	LdsStack<OVF, STACK_LDS> stk;
+__global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_FRAME_WAVES))) void k_frame(DScene S, DFrame F, uint8_t* __restrict__ out) {
+	__shared__ uint32_t s_stack[STACK_LDS * FRAME_BLOCK];
+	__shared__ uint32_t s_list[FRAME_BLOCK / WAVE][128];
+	LdsStack<OVF, STACK_LDS, FRAME_BLOCK> stk;
 	stk.lds = s_stack + threadIdx.x;
-	stk.ovf = OVF ? F.ovf + ((size_t)blockIdx.x * BLOCK + threadIdx.x) : nullptr;
+	stk.ovf = OVF ? F.ovf + ((size_t)blockIdx.x * FRAME_BLOCK + threadIdx.x) : nullptr;
 	stk.ovfStride = F.ovfStride;
 	const int lane = threadIdx.x & 63;
 	const unsigned long long ltMask = (1ull << lane) - 1ull;
@@ -1165,8 +1170,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_FRAM
 	// instead of sitting on a long queue of its own).  A wave's first batch is its own; later ones come from CTR_F_NCUR
 	// counters that hand out the batch numbers in turn -- one address sustains only ~88 atomics per microsecond, a 4K frame has
 	// 130 000 batches.  A wave starts at one counter and moves on to the next when that one has run out.
-	const uint32_t nWaves = gridDim.x * (BLOCK / WAVE);
-	const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6));
+	const uint32_t nWaves = gridDim.x * (FRAME_BLOCK / WAVE);
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (FRAME_BLOCK / WAVE) + (threadIdx.x >> 6));
 	const uint32_t nBatches = (F.nSlots + 63u) >> 6;
 	// (The number of the next batch is fetched only when the wave is ready for it: fetched ahead, every wave holds back one
 	// batch while it works on the hits of another, and the frame ends a whole batch's chain of rounds later.)
