@@ -288,14 +288,20 @@ struct mirt_scene {
 namespace {
 
 // ---- re-pack the flattened Partition tree into wide nodes ----------------------------------------------------------
+// Packs the reference tree as it is (MODE_REFWALK walks it): 64-byte nodes holding both children's boxes, chains of
+// single-child nodes skipped.  The recursion runs on one thread near the root and leaves subtrees of at most TASK_NODES
+// flat nodes to the thread pool; every subtree is packed into an array of its own, and the arrays are put one after the
+// other behind the top's with their node references moved by their offsets.
 struct Packer {
 	const mirt_scene_desc* d;
-	std::vector<float> wide;         // 16 floats per wide node
 	std::vector<uint32_t> leafPos;   // flat node index -> position in the leaf stream
-	std::vector<uint32_t> stream;    // count-prefixed leaf lists
-	std::vector<int64_t> primSlot;   // prim id -> tri index, or -1 - sphere index, or INT64_MIN
-	uint32_t maxDepth = 0;
-	bool bad = false;
+	static const uint32_t TASK_NODES = 1u << 16;
+	struct Out {
+		std::vector<float> wide;     // 16 floats per wide node
+		uint32_t maxDepth = 0;
+		bool bad = false;
+	};
+	struct Task { uint32_t node, depth, end, parent; int slot; };
 
 	static bool isLeaf(const mirt_node& n) { return (n.b & MIRT_LEAF_FLAG) != 0; }
 	static bool inside(const mirt_node& c, const mirt_node& p) {
@@ -315,19 +321,16 @@ struct Packer {
 			i = c;
 		}
 	}
-	uint32_t refOf(uint32_t flatIdx, uint32_t depth) {
-		const mirt_node& n = d->nodes[flatIdx];
-		if (isLeaf(n)) return REF_LEAF | leafPos[flatIdx];
-		return emit(flatIdx, depth);
-	}
-	uint32_t emit(uint32_t flatIdx, uint32_t depth) {
-		if (depth > maxDepth) maxDepth = depth;
-		if (depth > 4000) { bad = true; return REF_NONE; }
-		const uint32_t me = (uint32_t)(wide.size() / 16);
-		wide.resize(wide.size() + 16, 0.0f);
+	// `end`: one past the last flat index of the subtree (flat nodes are in pre-order); only the size of tasks depends on it
+	uint32_t emit(Out& o, uint32_t flatIdx, uint32_t depth, uint32_t end, std::vector<Task>* tasks) const {
+		if (depth > o.maxDepth) o.maxDepth = depth;
+		if (depth > 4000) { o.bad = true; return REF_NONE; }
+		const uint32_t me = (uint32_t)(o.wide.size() / 16);
+		o.wide.resize(o.wide.size() + 16, 0.0f);
 		const mirt_node n = d->nodes[flatIdx];
 		uint32_t refs[2] = {REF_NONE, REF_NONE};
 		const uint32_t ch[2] = {n.a, n.b};
+		const uint32_t chEnd[2] = {n.b != MIRT_NO_CHILD && n.b > n.a ? n.b : end, end};
 		float boxes[2][6];
 		for (int s = 0; s < 2; ++s) {
 			for (int k = 0; k < 6; ++k) boxes[s][k] = 0.0f;
@@ -335,14 +338,179 @@ struct Packer {
 			const uint32_t c = skipChain(ch[s]);
 			const mirt_node& cn = d->nodes[c];
 			for (int k = 0; k < 3; ++k) { boxes[s][k] = cn.bmin[k]; boxes[s][3 + k] = cn.bmax[k]; }
-			refs[s] = refOf(c, depth + 1);
+			if (isLeaf(cn)) refs[s] = REF_LEAF | leafPos[c];
+			else if (tasks && chEnd[s] > c && chEnd[s] - c <= TASK_NODES) tasks->push_back(Task{c, depth + 1, chEnd[s], me, s}); // reference patched in later
+			else refs[s] = emit(o, c, depth + 1, chEnd[s], tasks);
 		}
-		float* w = wide.data() + (size_t)me * 16;
+		float* w = o.wide.data() + (size_t)me * 16;
 		memcpy(w + 0, boxes[0], 12); memcpy(w + 3, &refs[0], 4);
 		memcpy(w + 4, boxes[0] + 3, 12); memcpy(w + 7, &refs[1], 4);
 		memcpy(w + 8, boxes[1], 12);
 		memcpy(w + 12, boxes[1] + 3, 12);
 		return me;
+	}
+	// the whole tree below interior node `root` into `wide`; returns false if it is too deep
+	bool run(uint32_t root, std::vector<float>& wide, uint32_t& maxDepth) const {
+		Out top;
+		std::vector<Task> tasks;
+		emit(top, root, 0, d->n_nodes, &tasks);
+		std::vector<Out> sub(tasks.size());
+		MirtPool::get().run((uint32_t)tasks.size(), [&](uint32_t t) {
+			sub[t].wide.reserve((size_t)(tasks[t].end - tasks[t].node) * 8);
+			emit(sub[t], tasks[t].node, tasks[t].depth, tasks[t].end, nullptr);
+		});
+		std::vector<size_t> base(tasks.size() + 1);
+		base[0] = top.wide.size() / 16;
+		bool bad = top.bad;
+		maxDepth = top.maxDepth;
+		for (size_t t = 0; t < tasks.size(); ++t) {
+			base[t + 1] = base[t] + sub[t].wide.size() / 16;
+			bad = bad || sub[t].bad;
+			if (sub[t].maxDepth > maxDepth) maxDepth = sub[t].maxDepth;
+		}
+		if (bad || base[tasks.size()] >= REF_LEAF) return false;
+		wide.swap(top.wide);
+		wide.resize(base[tasks.size()] * 16);
+		for (size_t t = 0; t < tasks.size(); ++t) {
+			const uint32_t r = (uint32_t)base[t];
+			memcpy(wide.data() + (size_t)tasks[t].parent * 16 + (tasks[t].slot ? 7 : 3), &r, 4);
+		}
+		MirtPool::get().run((uint32_t)tasks.size(), [&](uint32_t t) {
+			float* dst = wide.data() + base[t] * 16;
+			memcpy(dst, sub[t].wide.data(), sub[t].wide.size() * 4);
+			const uint32_t off = (uint32_t)base[t];
+			for (size_t i = 0; i < sub[t].wide.size() / 16; ++i)
+				for (int k = 3; k <= 7; k += 4) {
+					uint32_t r;
+					memcpy(&r, dst + i * 16 + k, 4);
+					if (r != REF_NONE && !(r & REF_LEAF)) { r += off; memcpy(dst + i * 16 + k, &r, 4); }
+				}
+			std::vector<float>().swap(sub[t].wide);
+		});
+		return true;
+	}
+};
+
+// Collapses the binary primitive hierarchy into 4-wide nodes with quantised child boxes (layout in mirt_device.h).
+// Parallel in the same way as Packer: one thread near the root, subtrees over at most TASK_PRIMS primitives on the pool.
+struct Collapser {
+	const BvhBuilder& bb;
+	const std::vector<uint32_t>& kindIndex;
+	static const uint32_t TASK_PRIMS = 1u << 15;
+	struct Out {
+		std::vector<uint32_t> w;     // 16 words per node
+		uint32_t maxDepth = 0, maxStack = 0;
+		uint32_t diag[8] = {0};
+	};
+	struct Task { int32_t node; uint32_t depth, acc, parent; int slot; };
+
+	uint32_t leafRef(const BvhNode& n) const {
+		return BVH_LEAF | (n.kind ? BVH_SPHERES : 0u) | ((n.count - 1) << BVH_COUNT_SHIFT) | kindIndex[n.first];
+	}
+	// acc: entries the walk can hold on its stack when it arrives at this node (siblings left behind by the ancestors)
+	uint32_t emit(Out& o, int32_t i, uint32_t depth, uint32_t acc, std::vector<Task>* tasks) const {
+		if (depth > o.maxDepth) o.maxDepth = depth;
+		const uint32_t me = (uint32_t)(o.w.size() / 16);
+		o.w.resize(o.w.size() + 16, 0u);
+		// up to four children: open the interior child with the largest surface area until none is left or there are four
+		int32_t ch[4] = { bb.nodes[i].left, bb.nodes[i].right, -1, -1 };
+		int n = 2;
+		while (n < 4) {
+			int best = -1;
+			float bestArea = -1.0f;
+			for (int k = 0; k < n; ++k) {
+				const BvhNode& c = bb.nodes[ch[k]];
+				if (c.left < 0) continue;
+				const float a = BvhBuilder::area(c.lo, c.hi);
+				if (a > bestArea) { bestArea = a; best = k; }
+			}
+			if (best < 0) break;
+			const BvhNode c = bb.nodes[ch[best]];
+			ch[best] = c.left;
+			ch[n++] = c.right;
+		}
+		const BvhNode& nd = bb.nodes[i];
+		uint32_t w[16] = {0};
+		uint32_t ex[3];
+		float scale[3];
+		for (int k = 0; k < 3; ++k) {
+			const double ext = (double)nd.hi[k] - (double)nd.lo[k];
+			int e = 0;
+			(void)frexp(ext / 255.0, &e); // ext/255 = m * 2^e, m in [0.5, 1): 2^e >= ext/255
+			int biased = e + 127;
+			if (!(ext > 0.0)) biased = 1;
+			if (biased < 1) biased = 1;
+			if (biased > 200) biased = 200;
+			ex[k] = (uint32_t)biased;
+			scale[k] = ldexpf(1.0f, biased - 127);
+			memcpy(&w[k], &nd.lo[k], 4);
+		}
+		w[3] = ((ex[0] - 127u) & 0xffu) | (((ex[1] - 127u) & 0xffu) << 8) | (((ex[2] - 127u) & 0xffu) << 16); // signed bytes
+		uint32_t refs[4] = { BVH_DONE, BVH_DONE, BVH_DONE, BVH_DONE };
+		for (int c = 0; c < 4; ++c) {
+			uint32_t qlo[3] = {255, 255, 255}, qhi[3] = {0, 0, 0};
+			if (c < n) {
+				const BvhNode& cn = bb.nodes[ch[c]];
+				for (int k = 0; k < 3; ++k) {
+					double a = floor(((double)cn.lo[k] - (double)nd.lo[k]) / (double)scale[k]);
+					double b = ceil(((double)cn.hi[k] - (double)nd.lo[k]) / (double)scale[k]);
+					if (a < 0.0) a = 0.0;
+					if (b > 255.0) b = 255.0; // cannot happen: 255 * scale >= the node's extent
+					if (b < a) b = a;
+					qlo[k] = (uint32_t)a;
+					qhi[k] = (uint32_t)b;
+				}
+			}
+			w[4] |= qlo[0] << (8 * c); w[5] |= qlo[1] << (8 * c); w[6] |= qlo[2] << (8 * c);
+			w[7] |= qhi[0] << (8 * c); w[8] |= qhi[1] << (8 * c); w[9] |= qhi[2] << (8 * c);
+		}
+		o.diag[1 + n]++;
+		const uint32_t below = acc + (uint32_t)n - 1u; // a step pushes every hit child but the one it goes to
+		if (below > o.maxStack) o.maxStack = below;
+		memcpy(o.w.data() + (size_t)me * 16, w, sizeof w);
+		for (int c = 0; c < n; ++c) {
+			const BvhNode& cn = bb.nodes[ch[c]];
+			if (cn.left < 0) refs[c] = leafRef(cn);
+			else if (tasks && cn.count <= TASK_PRIMS) tasks->push_back(Task{ch[c], depth + 1, below, me, c}); // patched in later
+			else refs[c] = emit(o, ch[c], depth + 1, below, tasks);
+		}
+		memcpy(o.w.data() + (size_t)me * 16 + 10, refs, sizeof refs);
+		return me;
+	}
+	// the hierarchy below interior node 0; returns the root's node index (0)
+	uint32_t run(std::vector<uint32_t>& out, uint32_t& maxDepth, uint32_t& maxStack, uint32_t* diag) const {
+		Out top;
+		std::vector<Task> tasks;
+		emit(top, 0, 1, 0, &tasks);
+		std::vector<Out> sub(tasks.size());
+		MirtPool::get().run((uint32_t)tasks.size(), [&](uint32_t t) {
+			sub[t].w.reserve((size_t)bb.nodes[tasks[t].node].count * 12);
+			emit(sub[t], tasks[t].node, tasks[t].depth, tasks[t].acc, nullptr);
+		});
+		std::vector<size_t> base(tasks.size() + 1);
+		base[0] = top.w.size() / 16;
+		maxDepth = top.maxDepth;
+		maxStack = top.maxStack;
+		for (int k = 0; k < 8; ++k) diag[k] += top.diag[k];
+		for (size_t t = 0; t < tasks.size(); ++t) {
+			base[t + 1] = base[t] + sub[t].w.size() / 16;
+			if (sub[t].maxDepth > maxDepth) maxDepth = sub[t].maxDepth;
+			if (sub[t].maxStack > maxStack) maxStack = sub[t].maxStack;
+			for (int k = 0; k < 8; ++k) diag[k] += sub[t].diag[k];
+		}
+		out.swap(top.w);
+		out.resize(base[tasks.size()] * 16);
+		for (size_t t = 0; t < tasks.size(); ++t) out[(size_t)tasks[t].parent * 16 + 10 + tasks[t].slot] = (uint32_t)base[t];
+		MirtPool::get().run((uint32_t)tasks.size(), [&](uint32_t t) {
+			uint32_t* dst = out.data() + base[t] * 16;
+			memcpy(dst, sub[t].w.data(), sub[t].w.size() * 4);
+			const uint32_t off = (uint32_t)base[t];
+			for (size_t i = 0; i < sub[t].w.size() / 16; ++i)
+				for (int k = 10; k < 14; ++k)
+					if (!(dst[i * 16 + k] & BVH_LEAF)) dst[i * 16 + k] += off;
+			std::vector<uint32_t>().swap(sub[t].w);
+		});
+		return 0;
 	}
 };
 
@@ -473,21 +641,86 @@ int scratch_init(int device) {
 	return MIRT_OK;
 }
 
-// fn(i) for every i < n on up to 16 threads; the iterations must not depend on each other
+// fn(i) for every i < n on the thread pool; the iterations must not depend on each other
 template <class F>
 void parallel_for(uint32_t n, F fn) {
-	unsigned nt = std::thread::hardware_concurrency();
-	nt = nt > 16 ? 16 : (nt < 1 ? 1 : nt);
-	if (n < 65536u || nt == 1) { for (uint32_t i = 0; i < n; ++i) fn(i); return; }
-	std::vector<std::thread> th;
-	const uint32_t per = (n + nt - 1) / nt;
-	for (unsigned t = 0; t < nt; ++t) {
-		const uint32_t a = t * per, b = a + per < n ? a + per : n;
-		if (a >= b) break;
-		th.emplace_back([=]() { for (uint32_t i = a; i < b; ++i) fn(i); });
-	}
-	for (auto& x : th) x.join();
+	MirtPool::get().for_each(n, 1u << 13, [&](uint64_t i) { fn((uint32_t)i); });
 }
+
+// A host array that is not initialised when it is allocated: the large ones (hundreds of megabytes) are written once, by
+// several threads, and zero-filling them first on one thread costs as much as computing them.
+template <class T>
+struct HostBuf {
+	T* p = nullptr;
+	size_t n = 0;
+	HostBuf() {}
+	HostBuf(const HostBuf&) = delete;
+	HostBuf& operator=(const HostBuf&) = delete;
+	~HostBuf() { free(p); }
+	bool alloc(size_t count) {
+		free(p);
+		n = count;
+		p = (T*)malloc(count * sizeof(T) + 16);
+		return p != nullptr;
+	}
+};
+
+// Host-to-device copies on a thread of their own, in the order they were asked for.  A source array must stay as it is
+// until finish() has returned.
+struct Uploader {
+	struct Item { DevBuf* b; const void* src; size_t bytes; };
+	int device;
+	std::thread t;
+	std::mutex m;
+	std::condition_variable cv;
+	std::vector<Item> q;
+	size_t head = 0;
+	bool closing = false, joined = false;
+	hipError_t err = hipSuccess;
+	explicit Uploader(int dev) : device(dev) { t = std::thread([this]() { loop(); }); }
+	~Uploader() { (void)finish(); }
+	void push(DevBuf& b, const void* src, size_t bytes) {
+		{
+			std::lock_guard<std::mutex> g(m);
+			q.push_back(Item{&b, src, bytes});
+		}
+		cv.notify_one();
+	}
+	int finish() {
+		if (!joined) {
+			{
+				std::lock_guard<std::mutex> g(m);
+				closing = true;
+			}
+			cv.notify_one();
+			t.join();
+			joined = true;
+		}
+		if (err != hipSuccess) return fail(MIRT_E_DEVICE, "scene upload: %s", hipGetErrorString(err));
+		return MIRT_OK;
+	}
+	void loop() {
+		hipError_t e = hipSetDevice(device);
+		for (;;) {
+			Item it;
+			{
+				std::unique_lock<std::mutex> g(m);
+				cv.wait(g, [&]() { return closing || head < q.size(); });
+				if (head >= q.size()) break;
+				it = q[head++];
+			}
+			if (e != hipSuccess) continue;
+			const size_t need = it.bytes ? it.bytes : 16;
+			if (need > it.b->bytes) {
+				if (it.b->p) { (void)hipFree(it.b->p); it.b->p = nullptr; it.b->bytes = 0; }
+				e = hipMalloc(&it.b->p, need);
+				if (e == hipSuccess) it.b->bytes = need;
+			}
+			if (e == hipSuccess && it.bytes) e = hipMemcpy(it.b->p, it.src, it.bytes, hipMemcpyHostToDevice);
+		}
+		err = e;
+	}
+};
 
 // a tree whose boxes are not nested is walked as it is, whatever mode was asked for
 int effective_mode(const mirt_scene* s, uint32_t mode) { return s->nested ? (int)mode : MODE_REFWALK; }
@@ -769,15 +1002,37 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		fprintf(stderr, "mirt_scene_create: %-28s %.3f s\n", name, std::chrono::duration<double>(now - tPhase).count());
 		tPhase = now;
 	};
+	// Host arrays that are uploaded live until the uploads have finished: they are declared before the uploader, which
+	// copies on a thread of its own while the next arrays are being prepared.
+	std::vector<int64_t> primSlot(d->n_prims);
+	std::vector<uint32_t> mCnt(d->n_prims, 0), mOfs((size_t)d->n_prims + 1, 0);
+	HostBuf<float> memb, tris, triX;
+	HostBuf<uint32_t> triInfo, refStream;
+	std::vector<float> sph, mats, lights, refWide;
+	std::vector<uint32_t> sphInfo, bvhWide;
+	mirt_scene* s = new (std::nothrow) mirt_scene();
+	if (!s) return fail(MIRT_E_NOMEM, "out of host memory");
+	s->device = device;
+	s->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	memset(&s->ds, 0, sizeof s->ds);
+	DScene& ds = s->ds;
+	Uploader up(device);
+	auto bail = [&](int err) {
+		const std::string keep = g_err;
+		(void)up.finish();
+		mirt_scene_destroy(s);
+		g_err = keep;
+		return err;
+	};
+
 	// primitive id -> triangle index, or -1 - sphere index; objects that are neither never hit (Shape.cpp:44-46)
-	std::vector<int64_t> primSlot(d->n_prims, INT64_MIN);
-	for (uint32_t i = 0; i < d->n_triangles; ++i) primSlot[d->tri_prim[i]] = (int64_t)i;
+	parallel_for(d->n_prims, [&](uint32_t i) { primSlot[i] = INT64_MIN; });
+	parallel_for(d->n_triangles, [&](uint32_t i) { primSlot[d->tri_prim[i]] = (int64_t)i; });
 	for (uint32_t i = 0; i < d->n_spheres; ++i) primSlot[d->sphere_prim[i]] = -1 - (int64_t)i;
 
 	// ---- membership lists: per primitive, the reference leaves holding it, in visiting order ------------------------
 	// (Nodes are handled in parallel: counts and slots by atomic increments, then every primitive's few entries are put
 	// into visiting order by their rank, so the lists do not depend on the thread count.)
-	std::vector<uint32_t> mCnt(d->n_prims, 0), mOfs(d->n_prims + 1, 0);
 	parallel_for(d->n_nodes, [&](uint32_t i) {
 		const mirt_node& n = d->nodes[i];
 		if (!(n.b & MIRT_LEAF_FLAG)) return;
@@ -785,34 +1040,39 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		for (uint32_t k = 0; k < cnt; ++k) __atomic_fetch_add(&mCnt[d->leaf_prims[n.a + k]], 1u, __ATOMIC_RELAXED);
 	});
 	for (uint32_t p = 0; p < d->n_prims; ++p) mOfs[p + 1] = mOfs[p] + mCnt[p];
-	std::vector<float> memb((size_t)mOfs[d->n_prims] * 8, 0.0f);
+	if (!memb.alloc((size_t)mOfs[d->n_prims] * 8)) return bail(fail(MIRT_E_NOMEM, "out of host memory"));
 	{
-		std::vector<uint32_t> fill(mOfs.begin(), mOfs.end() - 1);
+		std::vector<uint32_t> fill(d->n_prims);
+		parallel_for(d->n_prims, [&](uint32_t p) { fill[p] = mOfs[p]; });
 		parallel_for(d->n_nodes, [&](uint32_t i) {
 			const mirt_node& n = d->nodes[i];
 			if (!(n.b & MIRT_LEAF_FLAG)) return;
 			const uint32_t cnt = n.b & ~MIRT_LEAF_FLAG;
 			for (uint32_t k = 0; k < cnt; ++k) {
 				const uint32_t pos = n.a + k; // rank in the reference's visiting order
-				float* m = memb.data() + (size_t)__atomic_fetch_add(&fill[d->leaf_prims[pos]], 1u, __ATOMIC_RELAXED) * 8;
+				float* m = memb.p + (size_t)__atomic_fetch_add(&fill[d->leaf_prims[pos]], 1u, __ATOMIC_RELAXED) * 8;
 				m[0] = n.bmin[0]; m[1] = n.bmin[1]; m[2] = n.bmin[2]; memcpy(m + 3, &pos, 4);
 				m[4] = n.bmax[0]; m[5] = n.bmax[1]; m[6] = n.bmax[2]; m[7] = 0.0f;
 			}
 		});
 		parallel_for(d->n_prims, [&](uint32_t p) {
+			if (mCnt[p] < 2) return;
 			struct Entry { float f[8]; };
-			Entry* e = (Entry*)(memb.data() + (size_t)mOfs[p] * 8);
+			Entry* e = (Entry*)(memb.p + (size_t)mOfs[p] * 8);
 			std::sort(e, e + mCnt[p], [](const Entry& a, const Entry& b) { uint32_t x, y; memcpy(&x, a.f + 3, 4); memcpy(&y, b.f + 3, 4); return x < y; });
 		});
 	}
+	up.push(s->memb, memb.p, memb.n * 4);
 	// the hierarchy-plus-membership formulation needs child boxes nested in parent boxes (see mirt_bvh.h)
-	bool nested = true;
-	for (uint32_t i = 0; i < d->n_nodes && nested; ++i) {
+	std::atomic<bool> notNested(false);
+	parallel_for(d->n_nodes, [&](uint32_t i) {
 		const mirt_node& n = d->nodes[i];
-		if (n.b & MIRT_LEAF_FLAG) continue;
-		if (n.a != MIRT_NO_CHILD && !Packer::inside(d->nodes[n.a], n)) nested = false;
-		if (n.b != MIRT_NO_CHILD && !Packer::inside(d->nodes[n.b], n)) nested = false;
-	}
+		if (n.b & MIRT_LEAF_FLAG) return;
+		if (n.a != MIRT_NO_CHILD && !Packer::inside(d->nodes[n.a], n)) notNested.store(true, std::memory_order_relaxed);
+		if (n.b != MIRT_NO_CHILD && !Packer::inside(d->nodes[n.b], n)) notNested.store(true, std::memory_order_relaxed);
+	});
+	const bool nested = !notNested.load();
+	s->nested = nested;
 
 	phase("membership lists");
 	// ---- primitive hierarchy ---------------------------------------------------------------------------------------------
@@ -821,11 +1081,30 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	// ~1e-7 * |o - c|^2 / r of the surface (rounding of the quadratic).  D bounds |o|: rays start at the eye or on a surface.
 	BvhBuilder bb;
 	float slo[3] = {d->camera.look_from[0], d->camera.look_from[1], d->camera.look_from[2]}, shi[3] = {slo[0], slo[1], slo[2]};
-	for (uint32_t i = 0; i < d->n_triangles; ++i) {
-		const float* v = d->tri_verts + (size_t)i * 9;
-		for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) { slo[k] = fminf(slo[k], v[3 * c + k]); shi[k] = fmaxf(shi[k], v[3 * c + k]); }
+	const uint32_t GRAIN = 1u << 14;
+	const uint32_t triChunks = (d->n_triangles + GRAIN - 1) / GRAIN;
+	std::vector<uint32_t> chunkKept((size_t)triChunks + 1, 0);
+	{
+		// scene extent (min and max: the order of combination does not matter) and, per chunk, the triangles that sit in a leaf
+		struct Ext { float lo[3], hi[3]; };
+		std::vector<Ext> ext(triChunks);
+		MirtPool::get().run(triChunks, [&](uint32_t c) {
+			const uint32_t a = c * GRAIN, b = a + GRAIN < d->n_triangles ? a + GRAIN : d->n_triangles;
+			Ext e = {{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
+			uint32_t kept = 0;
+			for (uint32_t i = a; i < b; ++i) {
+				const float* v = d->tri_verts + (size_t)i * 9;
+				for (int q = 0; q < 3; ++q) for (int k = 0; k < 3; ++k) { e.lo[k] = fminf(e.lo[k], v[3 * q + k]); e.hi[k] = fmaxf(e.hi[k], v[3 * q + k]); }
+				kept += mCnt[d->tri_prim[i]] != 0 ? 1u : 0u; // in no leaf (dropped by Partition::insert, Partition.cpp:55-71): never tested
+			}
+			ext[c] = e;
+			chunkKept[c + 1] = kept;
+		});
+		for (const Ext& e : ext) for (int k = 0; k < 3; ++k) { slo[k] = fminf(slo[k], e.lo[k]); shi[k] = fmaxf(shi[k], e.hi[k]); }
+		for (uint32_t c = 0; c < triChunks; ++c) chunkKept[c + 1] += chunkKept[c];
 	}
 	std::vector<float> sphBox((size_t)d->n_spheres * 6);
+	uint32_t sphKept = 0;
 	for (uint32_t i = 0; i < d->n_spheres; ++i) {
 		const mirt_sphere& sp = d->spheres[i];
 		const float* M = sp.M;
@@ -837,213 +1116,86 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 			slo[k] = fminf(slo[k], c - h);
 			shi[k] = fmaxf(shi[k], c + h);
 		}
+		sphKept += mCnt[d->sphere_prim[i]] != 0 ? 1u : 0u;
 	}
 	const float D = sqrtf((shi[0] - slo[0]) * (shi[0] - slo[0]) + (shi[1] - slo[1]) * (shi[1] - slo[1]) + (shi[2] - slo[2]) * (shi[2] - slo[2]));
-	for (uint32_t i = 0; i < d->n_triangles; ++i) {
-		if (mCnt[d->tri_prim[i]] == 0) continue; // in no leaf (dropped by Partition::insert, Partition.cpp:55-71): never tested
-		const float* v = d->tri_verts + (size_t)i * 9;
-		BvhPrim p;
-		float maxabs = 0.0f;
-		for (int k = 0; k < 3; ++k) {
-			p.lo[k] = fminf(v[k], fminf(v[3 + k], v[6 + k]));
-			p.hi[k] = fmaxf(v[k], fmaxf(v[3 + k], v[6 + k]));
-			maxabs = fmaxf(maxabs, fmaxf(fabsf(p.lo[k]), fabsf(p.hi[k])));
+	const uint32_t triKept = chunkKept[triChunks];
+	bb.prims.resize((size_t)triKept + sphKept);
+	MirtPool::get().run(triChunks, [&](uint32_t c) {
+		const uint32_t a = c * GRAIN, b = a + GRAIN < d->n_triangles ? a + GRAIN : d->n_triangles;
+		BvhPrim* out = bb.prims.data() + chunkKept[c];
+		for (uint32_t i = a; i < b; ++i) {
+			if (mCnt[d->tri_prim[i]] == 0) continue;
+			const float* v = d->tri_verts + (size_t)i * 9;
+			BvhPrim p;
+			float maxabs = 0.0f;
+			for (int k = 0; k < 3; ++k) {
+				p.lo[k] = fminf(v[k], fminf(v[3 + k], v[6 + k]));
+				p.hi[k] = fmaxf(v[k], fmaxf(v[3 + k], v[6 + k]));
+				maxabs = fmaxf(maxabs, fmaxf(fabsf(p.lo[k]), fabsf(p.hi[k])));
+			}
+			const float pad = 1e-5f * (maxabs + D) + 1e-7f;
+			for (int k = 0; k < 3; ++k) { p.lo[k] -= pad; p.hi[k] += pad; }
+			p.ref = i;
+			p.kind = 0;
+			*out++ = p;
 		}
-		const float pad = 1e-5f * (maxabs + D) + 1e-7f;
-		for (int k = 0; k < 3; ++k) { p.lo[k] -= pad; p.hi[k] += pad; }
-		p.ref = i;
-		p.kind = 0;
-		bb.prims.push_back(p);
-	}
-	for (uint32_t i = 0; i < d->n_spheres; ++i) {
-		if (mCnt[d->sphere_prim[i]] == 0) continue;
-		BvhPrim p;
-		for (int k = 0; k < 3; ++k) {
-			const float c = sphBox[(size_t)i * 6 + k], h = sphBox[(size_t)i * 6 + 3 + k];
-			const float ratio = h > 0.0f ? D / h : 0.0f;
-			const float pad = h * (0.01f + 4e-7f * ratio * ratio) + 1e-5f * (fabsf(c) + D) + 1e-7f;
-			p.lo[k] = c - h - pad;
-			p.hi[k] = c + h + pad;
+	});
+	{
+		BvhPrim* out = bb.prims.data() + triKept;
+		for (uint32_t i = 0; i < d->n_spheres; ++i) {
+			if (mCnt[d->sphere_prim[i]] == 0) continue;
+			BvhPrim p;
+			for (int k = 0; k < 3; ++k) {
+				const float c = sphBox[(size_t)i * 6 + k], h = sphBox[(size_t)i * 6 + 3 + k];
+				const float ratio = h > 0.0f ? D / h : 0.0f;
+				const float pad = h * (0.01f + 4e-7f * ratio * ratio) + 1e-5f * (fabsf(c) + D) + 1e-7f;
+				p.lo[k] = c - h - pad;
+				p.hi[k] = c + h + pad;
+			}
+			p.ref = i;
+			p.kind = 1;
+			*out++ = p;
 		}
-		p.ref = i;
-		p.kind = 1;
-		bb.prims.push_back(p);
 	}
 	phase("primitive bounds");
 	bb.run();
 	phase("hierarchy build");
 
 	// primitives in hierarchy order (then the unreferenced ones), per kind
-	std::vector<uint32_t> triNew(d->n_triangles, 0xffffffffu), sphNew(d->n_spheres, 0xffffffffu), triOld, sphOld;
+	std::vector<uint32_t> triNew(d->n_triangles), sphNew(d->n_spheres, 0xffffffffu), triOld(d->n_triangles), sphOld;
 	std::vector<uint32_t> kindIndex(bb.prims.size());
-	for (size_t i = 0; i < bb.prims.size(); ++i) {
-		const BvhPrim& p = bb.prims[i];
-		if (p.kind == 0) { kindIndex[i] = (uint32_t)triOld.size(); triNew[p.ref] = (uint32_t)triOld.size(); triOld.push_back(p.ref); }
-		else { kindIndex[i] = (uint32_t)sphOld.size(); sphNew[p.ref] = (uint32_t)sphOld.size(); sphOld.push_back(p.ref); }
-	}
-	for (uint32_t i = 0; i < d->n_triangles; ++i) if (triNew[i] == 0xffffffffu) { triNew[i] = (uint32_t)triOld.size(); triOld.push_back(i); }
-	for (uint32_t i = 0; i < d->n_spheres; ++i) if (sphNew[i] == 0xffffffffu) { sphNew[i] = (uint32_t)sphOld.size(); sphOld.push_back(i); }
-	if (triOld.size() > BVH_FIRST_MASK || sphOld.size() > BVH_FIRST_MASK) return fail(MIRT_E_INVALID, "more than %u primitives of one kind", BVH_FIRST_MASK);
-
-	// 4-wide nodes with quantised child boxes (layout in mirt_device.h)
-	std::vector<uint32_t> bvhWide;
-	uint32_t bvhRoot = BVH_DONE, bvhWideDepth = 0, bvhMaxStack = 0;
-	uint32_t bvhDiag[8] = {0};
-	float bvhMin[3] = {0, 0, 0}, bvhMax[3] = {-1, -1, -1};
-	// (a serial recursion over the binary hierarchy: it runs on a thread of its own beside the packing of the reference
-	// tree and of the primitive records below, which need nothing from it; joined before its results are used)
-	struct Joiner {
-		std::thread t;
-		~Joiner() { if (t.joinable()) t.join(); }
-	} collapse;
-	collapse.t = std::thread([&]() {
-	if (!bb.nodes.empty()) {
-		struct Emit {
-			const BvhBuilder& bb;
-			const std::vector<uint32_t>& kindIndex;
-			std::vector<uint32_t>& out;
-			uint32_t maxDepth;
-			uint32_t* diag;
-			uint32_t leafRef(const BvhNode& n) const {
-				return BVH_LEAF | (n.kind ? BVH_SPHERES : 0u) | ((n.count - 1) << BVH_COUNT_SHIFT) | kindIndex[n.first];
+	parallel_for(d->n_triangles, [&](uint32_t i) { triNew[i] = 0xffffffffu; });
+	{
+		const uint32_t nP = (uint32_t)bb.prims.size(), chunks = (nP + GRAIN - 1) / GRAIN;
+		std::vector<uint32_t> triBefore((size_t)chunks + 1, 0);
+		MirtPool::get().run(chunks, [&](uint32_t c) {
+			const uint32_t a = c * GRAIN, b = a + GRAIN < nP ? a + GRAIN : nP;
+			uint32_t n = 0;
+			for (uint32_t i = a; i < b; ++i) n += bb.prims[i].kind == 0 ? 1u : 0u;
+			triBefore[c + 1] = n;
+		});
+		for (uint32_t c = 0; c < chunks; ++c) triBefore[c + 1] += triBefore[c];
+		sphOld.resize(nP - triBefore[chunks]);
+		MirtPool::get().run(chunks, [&](uint32_t c) {
+			const uint32_t a = c * GRAIN, b = a + GRAIN < nP ? a + GRAIN : nP;
+			uint32_t t = triBefore[c], sp = a - triBefore[c];
+			for (uint32_t i = a; i < b; ++i) {
+				const BvhPrim& p = bb.prims[i];
+				if (p.kind == 0) { kindIndex[i] = t; triNew[p.ref] = t; triOld[t] = p.ref; ++t; }
+				else { kindIndex[i] = sp; sphNew[p.ref] = sp; sphOld[sp] = p.ref; ++sp; }
 			}
-			uint32_t maxStack = 0;
-			// acc: entries the walk can hold on its stack when it arrives at this node (siblings left behind by the ancestors)
-			uint32_t emit(int32_t i, uint32_t depth, uint32_t acc = 0) {
-				if (depth > maxDepth) maxDepth = depth;
-				const uint32_t me = (uint32_t)(out.size() / 16);
-				out.resize(out.size() + 16, 0u);
-				// up to four children: open the interior child with the largest surface area until none is left or there are four
-				int32_t ch[4] = { bb.nodes[i].left, bb.nodes[i].right, -1, -1 };
-				int n = 2;
-				while (n < 4) {
-					int best = -1;
-					float bestArea = -1.0f;
-					for (int k = 0; k < n; ++k) {
-						const BvhNode& c = bb.nodes[ch[k]];
-						if (c.left < 0) continue;
-						const float a = BvhBuilder::area(c.lo, c.hi);
-						if (a > bestArea) { bestArea = a; best = k; }
-					}
-					if (best < 0) break;
-					const BvhNode c = bb.nodes[ch[best]];
-					ch[best] = c.left;
-					ch[n++] = c.right;
-				}
-				const BvhNode& nd = bb.nodes[i];
-				uint32_t w[16] = {0};
-				uint32_t ex[3];
-				float scale[3];
-				for (int k = 0; k < 3; ++k) {
-					const double ext = (double)nd.hi[k] - (double)nd.lo[k];
-					int e = 0;
-					(void)frexp(ext / 255.0, &e); // ext/255 = m * 2^e, m in [0.5, 1): 2^e >= ext/255
-					int biased = e + 127;
-					if (!(ext > 0.0)) biased = 1;
-					if (biased < 1) biased = 1;
-					if (biased > 200) biased = 200;
-					ex[k] = (uint32_t)biased;
-					scale[k] = ldexpf(1.0f, biased - 127);
-					memcpy(&w[k], &nd.lo[k], 4);
-				}
-				w[3] = ((ex[0] - 127u) & 0xffu) | (((ex[1] - 127u) & 0xffu) << 8) | (((ex[2] - 127u) & 0xffu) << 16); // signed bytes
-				uint32_t refs[4] = { BVH_DONE, BVH_DONE, BVH_DONE, BVH_DONE };
-				for (int c = 0; c < 4; ++c) {
-					uint32_t qlo[3] = {255, 255, 255}, qhi[3] = {0, 0, 0};
-					if (c < n) {
-						const BvhNode& cn = bb.nodes[ch[c]];
-						for (int k = 0; k < 3; ++k) {
-							double a = floor(((double)cn.lo[k] - (double)nd.lo[k]) / (double)scale[k]);
-							double b = ceil(((double)cn.hi[k] - (double)nd.lo[k]) / (double)scale[k]);
-							if (a < 0.0) a = 0.0;
-							if (b > 255.0) b = 255.0; // cannot happen: 255 * scale >= the node's extent
-							if (b < a) b = a;
-							qlo[k] = (uint32_t)a;
-							qhi[k] = (uint32_t)b;
-						}
-					}
-					w[4] |= qlo[0] << (8 * c); w[5] |= qlo[1] << (8 * c); w[6] |= qlo[2] << (8 * c);
-					w[7] |= qhi[0] << (8 * c); w[8] |= qhi[1] << (8 * c); w[9] |= qhi[2] << (8 * c);
-				}
-				diag[1 + n]++;
-				const uint32_t below = acc + (uint32_t)n - 1u; // a step pushes every hit child but the one it goes to
-				if (below > maxStack) maxStack = below;
-				memcpy(out.data() + (size_t)me * 16, w, sizeof w);
-				for (int c = 0; c < n; ++c) refs[c] = bb.nodes[ch[c]].left < 0 ? leafRef(bb.nodes[ch[c]]) : emit(ch[c], depth + 1, below);
-				memcpy(out.data() + (size_t)me * 16 + 10, refs, sizeof refs);
-				return me;
-			}
-		} em = {bb, kindIndex, bvhWide, 0, bvhDiag, 0};
-		for (const BvhNode& bn : bb.nodes) bvhDiag[bn.left < 0 ? 1 : 0]++;
-		bvhRoot = bb.nodes[0].left < 0 ? em.leafRef(bb.nodes[0]) : em.emit(0, 1);
-		bvhWideDepth = em.maxDepth;
-		bvhMaxStack = em.maxStack;
-		memcpy(bvhMin, bb.nodes[0].lo, 12);
-		memcpy(bvhMax, bb.nodes[0].hi, 12);
+		});
+		uint32_t nt = triBefore[chunks];
+		if (nt < d->n_triangles) for (uint32_t i = 0; i < d->n_triangles; ++i) if (triNew[i] == 0xffffffffu) { triNew[i] = nt; triOld[nt] = i; ++nt; }
+		for (uint32_t i = 0; i < d->n_spheres; ++i) if (sphNew[i] == 0xffffffffu) { sphNew[i] = (uint32_t)sphOld.size(); sphOld.push_back(i); }
 	}
-	});
-
-	// ---- the reference tree as it is (MODE_REFWALK) ------------------------------------------------------------------------
-	Packer pk;
-	pk.d = d;
-	pk.leafPos.assign(d->n_nodes, 0);
-	for (uint32_t i = 0; i < d->n_nodes; ++i) {
-		const mirt_node& n = d->nodes[i];
-		if (!(n.b & MIRT_LEAF_FLAG)) continue;
-		pk.leafPos[i] = (uint32_t)pk.stream.size();
-		const uint32_t cnt = n.b & ~MIRT_LEAF_FLAG;
-		const size_t at = pk.stream.size();
-		pk.stream.push_back(0);
-		uint32_t kept = 0;
-		for (uint32_t k = 0; k < cnt; ++k) {
-			const int64_t sl = primSlot[d->leaf_prims[n.a + k]];
-			if (sl == INT64_MIN) continue;
-			pk.stream.push_back(sl >= 0 ? triNew[(uint32_t)sl] : (PRIM_SPHERE | sphNew[(uint32_t)(-1 - sl)]));
-			++kept;
-		}
-		pk.stream[at] = kept;
-	}
-	if (pk.stream.size() >= 0x7fffffffull) return fail(MIRT_E_INVALID, "leaf stream too long");
-
-	mirt_scene* s = new (std::nothrow) mirt_scene();
-	if (!s) return fail(MIRT_E_NOMEM, "out of host memory");
-	s->device = device;
-	s->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-	s->nested = nested;
-	memset(&s->ds, 0, sizeof s->ds);
-	DScene& ds = s->ds;
-	ds.rootRef = REF_NONE;
-	ds.refCull = d->n_spheres == 0 ? 1u : 0u;
-	for (int k = 0; k < 3; ++k) { ds.rootMin[k] = 0.0f; ds.rootMax[k] = -1.0f; }
-	if (d->n_nodes) {
-		const uint32_t r = pk.skipChain(0);
-		const mirt_node& rn = d->nodes[r];
-		for (int k = 0; k < 3; ++k) { ds.rootMin[k] = rn.bmin[k]; ds.rootMax[k] = rn.bmax[k]; }
-		ds.rootRef = pk.refOf(r, 0);
-		if (pk.bad || pk.maxDepth + 2 > STACK_MAX) {
-			delete s;
-			return fail(MIRT_E_INVALID, "Partition tree depth %u exceeds the traversal stack (%d)", pk.maxDepth, STACK_MAX);
-		}
-	}
-	s->wideDepth = pk.maxDepth;
-	collapse.t.join();
-	phase("reference tree pack (hierarchy collapse beside it)");
-	s->bvhDepth = bvhWideDepth;
-	// Long walks (big scenes) make refilling idle lanes pay; short ones do not (see k_trace).  MIRT_REFILL_MIN overrides.
-	s->refillMin = bvhWide.size() / 16 > 500000u ? 36u : 64u;
-	if (const char* env = getenv("MIRT_SINGLE_LAUNCH")) s->singleLaunch = atoi(env) != 0;
-	if (const char* env = getenv("MIRT_COPY_THREADS")) { const int v = atoi(env); if (v >= 0 && v <= 32) s->copyThreads = v; }
-	if (const char* env = getenv("MIRT_REFILL_MIN")) { const int v = atoi(env); if (v >= 1 && v <= 64) s->refillMin = (uint32_t)v; }
-	memcpy(s->diag, bvhDiag, sizeof bvhDiag);
-	ds.bvhRoot = bvhRoot;
-	memcpy(ds.bvhMin, bvhMin, 12);
-	memcpy(ds.bvhMax, bvhMax, 12);
+	if (triOld.size() > BVH_FIRST_MASK || sphOld.size() > BVH_FIRST_MASK) return bail(fail(MIRT_E_INVALID, "more than %u primitives of one kind", BVH_FIRST_MASK));
 
 	// triangles in hierarchy order: { N, dot(v1,N) } { v3, E } { a0, c1 } { a1, K } and { v1, area } { v2, 0 }
 	// (E, a_i, c1, K: tri_hit's filter)
-	std::vector<float> tris((size_t)d->n_triangles * TRI_F4 * 4, 0.0f);
-	std::vector<float> triX((size_t)d->n_triangles * 8, 0.0f);
-	std::vector<uint32_t> triInfo((size_t)d->n_triangles * 4, 0);
+	if (!tris.alloc((size_t)d->n_triangles * TRI_F4 * 4) || !triX.alloc((size_t)d->n_triangles * 8) || !triInfo.alloc((size_t)d->n_triangles * 4))
+		return bail(fail(MIRT_E_NOMEM, "out of host memory"));
 	parallel_for(d->n_triangles, [&](uint32_t ni) {
 		const uint32_t i = triOld[ni];
 		const float* v = d->tri_verts + (size_t)i * 9;
@@ -1052,19 +1204,22 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		const float dv = hdot(v1, N);                                // Triangle.cpp:153
 		const h3 e1 = hsub(v3, v2), e2 = hsub(v1, v3);               // Triangle.cpp:148-149
 		const float area = hdot(hcross(e1, e2), N) / 2.0f;           // Triangle.cpp:162
-		float* t = tris.data() + (size_t)ni * TRI_F4 * 4;
+		float* t = tris.p + (size_t)ni * TRI_F4 * 4;
 		t[0] = N.x; t[1] = N.y; t[2] = N.z; t[3] = dv;
 		tri_filter(t + 4, N, v1, v2, v3, area);
-		float* x = triX.data() + (size_t)ni * 8;
+		float* x = triX.p + (size_t)ni * 8;
 		x[0] = v1.x; x[1] = v1.y; x[2] = v1.z; x[3] = area;
-		x[4] = v2.x; x[5] = v2.y; x[6] = v2.z;
+		x[4] = v2.x; x[5] = v2.y; x[6] = v2.z; x[7] = 0.0f;
 		const uint32_t prim = d->tri_prim[i];
-		uint32_t* inf = triInfo.data() + (size_t)ni * 4;
+		uint32_t* inf = triInfo.p + (size_t)ni * 4;
 		inf[0] = prim; inf[1] = d->prim_material[prim]; inf[2] = mOfs[prim]; inf[3] = mCnt[prim];
 	});
+	up.push(s->tris, tris.p, tris.n * 4);
+	up.push(s->triX, triX.p, triX.n * 4);
+	up.push(s->triInfo, triInfo.p, triInfo.n * 4);
 	// spheres: { c, powf(r,2) } M[4] Minv[4]
-	std::vector<float> sph((size_t)d->n_spheres * SPHERE_F4 * 4, 0.0f);
-	std::vector<uint32_t> sphInfo((size_t)d->n_spheres * 4, 0);
+	sph.assign((size_t)d->n_spheres * SPHERE_F4 * 4, 0.0f);
+	sphInfo.assign((size_t)d->n_spheres * 4, 0);
 	for (uint32_t ni = 0; ni < d->n_spheres; ++ni) {
 		const uint32_t i = sphOld[ni];
 		const mirt_sphere& sp = d->spheres[i];
@@ -1077,7 +1232,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		uint32_t* inf = sphInfo.data() + (size_t)ni * 4;
 		inf[0] = prim; inf[1] = d->prim_material[prim]; inf[2] = mOfs[prim]; inf[3] = mCnt[prim];
 	}
-	std::vector<float> mats((size_t)d->n_materials * 16, 0.0f);
+	mats.assign((size_t)d->n_materials * 16, 0.0f);
 	for (uint32_t i = 0; i < d->n_materials; ++i) {
 		const mirt_material& m = d->materials[i];
 		float* t = mats.data() + (size_t)i * 16;
@@ -1086,23 +1241,116 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		t[8] = m.emission[0]; t[9] = m.emission[1]; t[10] = m.emission[2];
 		t[12] = m.ambient[0]; t[13] = m.ambient[1]; t[14] = m.ambient[2];
 	}
-	std::vector<float> lights((size_t)d->n_lights * 8, 0.0f);
+	lights.assign((size_t)d->n_lights * 8, 0.0f);
 	for (uint32_t i = 0; i < d->n_lights; ++i) {
 		const mirt_light& l = d->lights[i];
 		float* t = lights.data() + (size_t)i * 8;
 		memcpy(t, l.location, 16);
 		memcpy(t + 4, l.color, 12);
 	}
+	up.push(s->spheres, sph.data(), sph.size() * 4);
+	up.push(s->sphInfo, sphInfo.data(), sphInfo.size() * 4);
+	up.push(s->materials, mats.data(), mats.size() * 4);
+	up.push(s->lights, lights.data(), lights.size() * 4);
+	phase("primitive records");
+
+	// 4-wide nodes with quantised child boxes (layout in mirt_device.h)
+	uint32_t bvhRoot = BVH_DONE, bvhWideDepth = 0, bvhMaxStack = 0;
+	uint32_t bvhDiag[8] = {0};
+	float bvhMin[3] = {0, 0, 0}, bvhMax[3] = {-1, -1, -1};
+	if (!bb.nodes.empty()) {
+		const Collapser col = {bb, kindIndex};
+		for (const BvhNode& bn : bb.nodes) bvhDiag[bn.left < 0 ? 1 : 0]++;
+		bvhRoot = bb.nodes[0].left < 0 ? col.leafRef(bb.nodes[0]) : col.run(bvhWide, bvhWideDepth, bvhMaxStack, bvhDiag);
+		memcpy(bvhMin, bb.nodes[0].lo, 12);
+		memcpy(bvhMax, bb.nodes[0].hi, 12);
+	}
+	up.push(s->bvh, bvhWide.data(), bvhWide.size() * 4);
+	phase("hierarchy collapse");
+
+	// ---- the reference tree as it is (MODE_REFWALK) ------------------------------------------------------------------------
+	// leaf stream: per leaf a count and the primitives that can be hit at all, under their hierarchy-order numbers
+	Packer pk;
+	pk.d = d;
+	pk.leafPos.resize(d->n_nodes);
+	{
+		const uint32_t chunks = (d->n_nodes + GRAIN - 1) / GRAIN;
+		std::vector<uint64_t> words((size_t)chunks + 1, 0);
+		MirtPool::get().run(chunks, [&](uint32_t c) {
+			const uint32_t a = c * GRAIN, b = a + GRAIN < d->n_nodes ? a + GRAIN : d->n_nodes;
+			uint64_t w = 0;
+			for (uint32_t i = a; i < b; ++i) {
+				const mirt_node& n = d->nodes[i];
+				if (!(n.b & MIRT_LEAF_FLAG)) continue;
+				const uint32_t cnt = n.b & ~MIRT_LEAF_FLAG;
+				w += 1;
+				for (uint32_t k = 0; k < cnt; ++k) w += primSlot[d->leaf_prims[n.a + k]] != INT64_MIN ? 1u : 0u;
+			}
+			words[c + 1] = w;
+		});
+		for (uint32_t c = 0; c < chunks; ++c) words[c + 1] += words[c];
+		if (words[chunks] >= 0x7fffffffull) return bail(fail(MIRT_E_INVALID, "leaf stream too long"));
+		if (!refStream.alloc((size_t)words[chunks])) return bail(fail(MIRT_E_NOMEM, "out of host memory"));
+		MirtPool::get().run(chunks, [&](uint32_t c) {
+			const uint32_t a = c * GRAIN, b = a + GRAIN < d->n_nodes ? a + GRAIN : d->n_nodes;
+			uint32_t at = (uint32_t)words[c];
+			for (uint32_t i = a; i < b; ++i) {
+				const mirt_node& n = d->nodes[i];
+				pk.leafPos[i] = 0;
+				if (!(n.b & MIRT_LEAF_FLAG)) continue;
+				pk.leafPos[i] = at;
+				const uint32_t cnt = n.b & ~MIRT_LEAF_FLAG;
+				uint32_t kept = 0;
+				for (uint32_t k = 0; k < cnt; ++k) {
+					const int64_t sl = primSlot[d->leaf_prims[n.a + k]];
+					if (sl == INT64_MIN) continue;
+					refStream.p[at + 1 + kept] = sl >= 0 ? triNew[(uint32_t)sl] : (PRIM_SPHERE | sphNew[(uint32_t)(-1 - sl)]);
+					++kept;
+				}
+				refStream.p[at] = kept;
+				at += 1 + kept;
+			}
+		});
+	}
+	up.push(s->leafs, refStream.p, refStream.n * 4);
+	ds.rootRef = REF_NONE;
+	ds.refCull = d->n_spheres == 0 ? 1u : 0u;
+	for (int k = 0; k < 3; ++k) { ds.rootMin[k] = 0.0f; ds.rootMax[k] = -1.0f; }
+	uint32_t refDepth = 0;
+	if (d->n_nodes) {
+		const uint32_t r = pk.skipChain(0);
+		const mirt_node& rn = d->nodes[r];
+		for (int k = 0; k < 3; ++k) { ds.rootMin[k] = rn.bmin[k]; ds.rootMax[k] = rn.bmax[k]; }
+		if (Packer::isLeaf(rn)) ds.rootRef = REF_LEAF | pk.leafPos[r];
+		else {
+			ds.rootRef = 0;
+			if (!pk.run(r, refWide, refDepth) || refDepth + 2 > STACK_MAX)
+				return bail(fail(MIRT_E_INVALID, "Partition tree depth %u exceeds the traversal stack (%d)", refDepth, STACK_MAX));
+		}
+	}
+	up.push(s->nodes, refWide.data(), refWide.size() * 4);
+	s->wideDepth = refDepth;
+	phase("reference tree pack");
+	s->bvhDepth = bvhWideDepth;
+	// Long walks (big scenes) make refilling idle lanes pay; short ones do not (see k_trace).  MIRT_REFILL_MIN overrides.
+	s->refillMin = bvhWide.size() / 16 > 500000u ? 36u : 64u;
+	if (const char* env = getenv("MIRT_SINGLE_LAUNCH")) s->singleLaunch = atoi(env) != 0;
+	if (const char* env = getenv("MIRT_COPY_THREADS")) { const int v = atoi(env); if (v >= 0 && v <= 32) s->copyThreads = v; }
+	if (const char* env = getenv("MIRT_REFILL_MIN")) { const int v = atoi(env); if (v >= 1 && v <= 64) s->refillMin = (uint32_t)v; }
+	memcpy(s->diag, bvhDiag, sizeof bvhDiag);
+	ds.bvhRoot = bvhRoot;
+	memcpy(ds.bvhMin, bvhMin, 12);
+	memcpy(ds.bvhMax, bvhMax, 12);
 	// camera basis (Camera.cpp:4-7,16-19): identical for every pixel, so evaluated once here
 	{
 		const mirt_camera& c = d->camera;
 		const h3 from = H3(c.look_from[0], c.look_from[1], c.look_from[2]);
 		const h3 at = H3(c.look_at[0], c.look_at[1], c.look_at[2]);
-		const h3 up = H3(c.up[0], c.up[1], c.up[2]);
+		const h3 up3 = H3(c.up[0], c.up[1], c.up[2]);
 		const h3 fwd = hsub(at, from);
 		const h3 nf = hnorm(fwd);
 		const h3 w = H3(-nf.x, -nf.y, -nf.z);
-		const h3 u = hnorm(hcross(up, w));
+		const h3 u = hnorm(hcross(up3, w));
 		const h3 v = hnorm(hcross(w, u));
 		ds.cam.eye[0] = from.x; ds.cam.eye[1] = from.y; ds.cam.eye[2] = from.z;
 		ds.cam.u[0] = u.x; ds.cam.u[1] = u.y; ds.cam.u[2] = u.z;
@@ -1131,18 +1379,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	s->nLights = d->n_lights;
 	s->maxDepth = d->max_depth;
 
-	phase("primitive records");
-	e = upload(s->nodes, pk.wide.data(), pk.wide.size() * 4);
-	if (!e) e = upload(s->leafs, pk.stream.data(), pk.stream.size() * 4);
-	if (!e) e = upload(s->bvh, bvhWide.data(), bvhWide.size() * 4);
-	if (!e) e = upload(s->memb, memb.data(), memb.size() * 4);
-	if (!e) e = upload(s->tris, tris.data(), tris.size() * 4);
-	if (!e) e = upload(s->triX, triX.data(), triX.size() * 4);
-	if (!e) e = upload(s->triInfo, triInfo.data(), triInfo.size() * 4);
-	if (!e) e = upload(s->spheres, sph.data(), sph.size() * 4);
-	if (!e) e = upload(s->sphInfo, sphInfo.data(), sphInfo.size() * 4);
-	if (!e) e = upload(s->materials, mats.data(), mats.size() * 4);
-	if (!e) e = upload(s->lights, lights.data(), lights.size() * 4);
+	e = up.finish();
 	if (!e) { e = s->dbg.ensure(32 * 8); if (!e) (void)hipMemset(s->dbg.p, 0, 32 * 8); }
 	ds.dbg = (unsigned long long*)s->dbg.p;
 	s->ovfStride = (uint32_t)s->numCUs * GRID_BLOCKS_PER_CU * BLOCK;
@@ -1156,13 +1393,8 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	s->ovfLevels = s->deepBvh ? stackNeed - ldsEntries : 0u;
 	if (!e && s->deepBvh) e = s->hookOvf.ensure((size_t)s->ovfLevels * s->ovfStride * 4);
 	if (!e && hipStreamCreate(&s->stream) != hipSuccess) e = fail(MIRT_E_DEVICE, "hipStreamCreate failed");
-	if (e) {
-		std::string keep = g_err;
-		mirt_scene_destroy(s);
-		g_err = keep;
-		return e;
-	}
-	phase("upload");
+	if (e) return bail(e);
+	phase("upload (what was left of it)");
 	ds.nodes = (const float4*)s->nodes.p;
 	ds.leafs = (const uint32_t*)s->leafs.p;
 	ds.bvh = (const float4*)s->bvh.p;

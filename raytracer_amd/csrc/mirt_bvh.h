@@ -21,13 +21,17 @@
 #include <thread>
 #include <vector>
 
+#include "mirt_pool.h"
+
 struct BvhPrim {
+	BvhPrim() {} // no initialisation: arrays of millions are resized and then filled by several threads
 	float lo[3], hi[3];
 	uint32_t ref; // caller's handle
 	uint32_t kind; // 0 triangle, 1 sphere: leaves are homogeneous
 };
 
 struct BvhNode {
+	BvhNode() {} // (as BvhPrim)
 	float lo[3], hi[3];
 	int32_t left, right; // children, or -1/-1 for a leaf
 	uint32_t first, count; // leaf: range in the ordered primitive list
@@ -51,14 +55,59 @@ struct BvhBuilder {
 	std::vector<BvhNode> nodes;
 	uint32_t maxDepth = 0;
 
-	// Parallel build: the recursion runs on one thread down to ranges of at most CUT primitives; those ranges are
-	// independent (each works inside its own part of `prims`), so they are built on several threads into node arrays of
-	// their own and spliced in afterwards.  CUT does not depend on the thread count: the tree is the same for any.
+	// Parallel build.  Ranges of more than CUT primitives (the top of the tree: few nodes, each over a large part of the
+	// array) are split by passes that run on all threads -- bounds, binning and a stable partition, each over fixed chunks
+	// of GRAIN primitives whose partial results are combined in chunk order.  Ranges of at most CUT primitives are
+	// independent (each works inside its own part of `prims`): they are built whole, one per thread at a time, into node
+	// arrays of their own and spliced in afterwards.  Neither CUT nor GRAIN depends on the thread count: the tree is the
+	// same for any.
 	static const uint32_t CUT = 1u << 16;
+	static const uint32_t GRAIN = 1u << 14;
 	struct Task { uint32_t start, end, depth; };
 	std::vector<Task> tasks;
 	bool cutting = false;
 	BvhPrim* P = nullptr; // the array build() works on
+	BvhPrim* tmp = nullptr; // as large as `prims`: the partition of a large range goes through it
+
+	struct Bins {
+		uint32_t bc[3][BINS];
+		float blo[3][BINS][3], bhi[3][BINS][3];
+		void clear() {
+			for (int a = 0; a < 3; ++a) for (int b = 0; b < BINS; ++b) { bc[a][b] = 0; for (int k = 0; k < 3; ++k) { blo[a][b][k] = INFINITY; bhi[a][b][k] = -INFINITY; } }
+		}
+	};
+	static int bin_of(const BvhPrim& p, int ax, float clo, float scale) {
+		const float c = 0.5f * (p.lo[ax] + p.hi[ax]);
+		const int b = (int)((c - clo) * scale);
+		return b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+	}
+	// stable partition of [start, end) by pred, chunk by chunk through `tmp`; returns the first index of the second part
+	template <class Pred>
+	uint32_t partition_large(uint32_t start, uint32_t end, Pred pred) {
+		const uint32_t nChunks = (end - start + GRAIN - 1) / GRAIN;
+		std::vector<uint32_t> nTrue(nChunks + 1, 0);
+		MirtPool::get().run(nChunks, [&](uint32_t c) {
+			const uint32_t a = start + c * GRAIN, b = a + GRAIN < end ? a + GRAIN : end;
+			uint32_t n = 0;
+			for (uint32_t i = a; i < b; ++i) n += pred(P[i]) ? 1u : 0u;
+			nTrue[c + 1] = n;
+		});
+		for (uint32_t c = 0; c < nChunks; ++c) nTrue[c + 1] += nTrue[c];
+		const uint32_t mid = start + nTrue[nChunks];
+		MirtPool::get().run(nChunks, [&](uint32_t c) {
+			const uint32_t a = start + c * GRAIN, b = a + GRAIN < end ? a + GRAIN : end;
+			uint32_t t = start + nTrue[c], f = mid + (a - start) - nTrue[c];
+			for (uint32_t i = a; i < b; ++i) {
+				if (pred(P[i])) tmp[t++] = P[i];
+				else tmp[f++] = P[i];
+			}
+		});
+		MirtPool::get().run(nChunks, [&](uint32_t c) {
+			const uint32_t a = start + c * GRAIN, b = a + GRAIN < end ? a + GRAIN : end;
+			memcpy(P + a, tmp + a, (size_t)(b - a) * sizeof(BvhPrim));
+		});
+		return mid;
+	}
 
 	static float area(const float* lo, const float* hi) {
 		const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
@@ -82,7 +131,29 @@ struct BvhBuilder {
 		float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
 		float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
 		bool mixed = false;
-		for (uint32_t i = start; i < end; ++i) {
+		const bool large = tmp && end - start > CUT;
+		const uint32_t nChunks = large ? (end - start + GRAIN - 1) / GRAIN : 1u;
+		if (large) {
+			struct Part { float lo[3], hi[3], clo[3], chi[3]; bool mixed; };
+			std::vector<Part> part(nChunks);
+			const uint32_t kind0 = P[start].kind;
+			MirtPool::get().run(nChunks, [&](uint32_t ch) {
+				const uint32_t a = start + ch * GRAIN, b = a + GRAIN < end ? a + GRAIN : end;
+				Part q;
+				for (int k = 0; k < 3; ++k) { q.lo[k] = q.clo[k] = INFINITY; q.hi[k] = q.chi[k] = -INFINITY; }
+				q.mixed = false;
+				for (uint32_t i = a; i < b; ++i) {
+					grow(q.lo, q.hi, P[i].lo, P[i].hi);
+					float c[3];
+					for (int k = 0; k < 3; ++k) c[k] = 0.5f * (P[i].lo[k] + P[i].hi[k]);
+					grow(q.clo, q.chi, c, c);
+					q.mixed |= P[i].kind != kind0;
+				}
+				part[ch] = q;
+			});
+			for (const Part& q : part) { grow(lo, hi, q.lo, q.hi); grow(clo, chi, q.clo, q.chi); mixed |= q.mixed; }
+		}
+		else for (uint32_t i = start; i < end; ++i) {
 			grow(lo, hi, P[i].lo, P[i].hi);
 			float c[3];
 			for (int k = 0; k < 3; ++k) c[k] = 0.5f * (P[i].lo[k] + P[i].hi[k]);
@@ -113,20 +184,52 @@ struct BvhBuilder {
 			if (ext > 0.0f && depth < (uint32_t)SAH_DEPTH) {
 				float bestCost = INFINITY, bestScale = 0.0f;
 				int bestBin = -1, bestAxis = -1;
+				// a large range is binned along all three axes in one pass over its chunks
+				Bins* all = nullptr;
+				std::vector<Bins> partBins;
+				Bins total;
+				if (large) {
+					partBins.resize(nChunks);
+					float sc[3];
+					for (int ax = 0; ax < 3; ++ax) sc[ax] = chi[ax] - clo[ax] > 0.0f ? (float)BINS / (chi[ax] - clo[ax]) : 0.0f;
+					MirtPool::get().run(nChunks, [&](uint32_t ch) {
+						const uint32_t a = start + ch * GRAIN, b = a + GRAIN < end ? a + GRAIN : end;
+						Bins& q = partBins[ch];
+						q.clear();
+						for (uint32_t i = a; i < b; ++i) {
+							for (int ax = 0; ax < 3; ++ax) {
+								if (!(sc[ax] > 0.0f)) continue;
+								const int bi = bin_of(P[i], ax, clo[ax], sc[ax]);
+								q.bc[ax][bi]++;
+								grow(q.blo[ax][bi], q.bhi[ax][bi], P[i].lo, P[i].hi);
+							}
+						}
+					});
+					total.clear();
+					for (const Bins& q : partBins)
+						for (int ax = 0; ax < 3; ++ax) for (int b = 0; b < BINS; ++b) {
+							total.bc[ax][b] += q.bc[ax][b];
+							grow(total.blo[ax][b], total.bhi[ax][b], q.blo[ax][b], q.bhi[ax][b]);
+						}
+					all = &total;
+				}
 				for (int ax = 0; ax < 3; ++ax) {
 					const float e = chi[ax] - clo[ax];
 					if (!(e > 0.0f)) continue;
-					uint32_t bc[BINS] = {0};
-					float blo[BINS][3], bhi[BINS][3];
-					for (int b = 0; b < BINS; ++b) for (int k = 0; k < 3; ++k) { blo[b][k] = INFINITY; bhi[b][k] = -INFINITY; }
+					uint32_t bcLocal[BINS] = {0};
+					float bloLocal[BINS][3], bhiLocal[BINS][3];
 					const float scale = (float)BINS / e;
-					for (uint32_t i = start; i < end; ++i) {
-						const float c = 0.5f * (P[i].lo[ax] + P[i].hi[ax]);
-						int b = (int)((c - clo[ax]) * scale);
-						b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
-						bc[b]++;
-						grow(blo[b], bhi[b], P[i].lo, P[i].hi);
+					if (!all) {
+						for (int b = 0; b < BINS; ++b) for (int k = 0; k < 3; ++k) { bloLocal[b][k] = INFINITY; bhiLocal[b][k] = -INFINITY; }
+						for (uint32_t i = start; i < end; ++i) {
+							const int b = bin_of(P[i], ax, clo[ax], scale);
+							bcLocal[b]++;
+							grow(bloLocal[b], bhiLocal[b], P[i].lo, P[i].hi);
+						}
 					}
+					const uint32_t* bc = all ? all->bc[ax] : bcLocal;
+					const float (*blo)[3] = all ? all->blo[ax] : bloLocal;
+					const float (*bhi)[3] = all ? all->bhi[ax] : bhiLocal;
 					float rightArea[BINS];
 					uint32_t rightCnt[BINS];
 					float rlo[3] = {INFINITY, INFINITY, INFINITY}, rhi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -155,12 +258,8 @@ struct BvhBuilder {
 					const int ax = bestAxis;
 					const float ca = clo[ax], scale = bestScale;
 					const int bb = bestBin;
-					mid = (uint32_t)(std::partition(P + start, P + end, [=](const BvhPrim& p) {
-						const float c = 0.5f * (p.lo[ax] + p.hi[ax]);
-						int b = (int)((c - ca) * scale);
-						b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
-						return b <= bb;
-					}) - P);
+					auto goesLeft = [=](const BvhPrim& p) { return bin_of(p, ax, ca, scale) <= bb; };
+					mid = large ? partition_large(start, end, goesLeft) : (uint32_t)(std::partition(P + start, P + end, goesLeft) - P);
 					done = mid > start && mid < end;
 				}
 			}
@@ -188,53 +287,53 @@ struct BvhBuilder {
 		tasks.clear();
 		maxDepth = 0;
 		if (prims.empty()) return;
-		nodes.reserve(prims.size() / 2);
+		if (prims.size() <= 4u * CUT) nodes.reserve(prims.size());
 		cutting = prims.size() > 4u * CUT;
 		P = prims.data();
+		std::vector<BvhPrim> scratch;
+		if (cutting) scratch.resize(prims.size());
+		tmp = cutting ? scratch.data() : nullptr;
 		build(0, (uint32_t)prims.size(), 0);
 		cutting = false;
+		tmp = nullptr;
+		std::vector<BvhPrim>().swap(scratch);
 		if (tasks.empty()) return;
-		unsigned nThreads = std::thread::hardware_concurrency();
-		if (nThreads > 16) nThreads = 16;
-		if (nThreads < 1) nThreads = 1;
-		if (nThreads > tasks.size()) nThreads = (unsigned)tasks.size();
 		std::vector<std::vector<BvhNode>> sub(tasks.size());
 		std::vector<uint32_t> subDepth(tasks.size(), 0);
-		std::atomic<size_t> next(0);
-		auto work = [&]() {
-			BvhBuilder local; // shares nothing but the primitives of its tasks' ranges
+		MirtPool::get().run((uint32_t)tasks.size(), [&](uint32_t t) {
+			BvhBuilder local; // shares nothing but the primitives of its task's range (ranges of different tasks are disjoint)
 			local.LEAF_MIN = LEAF_MIN;
 			local.COST_PRIM = COST_PRIM;
-			for (;;) {
-				const size_t t = next.fetch_add(1);
-				if (t >= tasks.size()) break;
-				local.nodes.clear();
-				local.maxDepth = 0;
-				local.P = prims.data(); // ranges of different tasks are disjoint
-				local.build(tasks[t].start, tasks[t].end, tasks[t].depth);
-				sub[t].swap(local.nodes);
-				subDepth[t] = local.maxDepth;
-			}
-		};
-		std::vector<std::thread> th;
-		for (unsigned i = 1; i < nThreads; ++i) th.emplace_back(work);
-		work();
-		for (auto& t : th) t.join();
+			local.P = prims.data();
+			local.nodes.reserve((size_t)(tasks[t].end - tasks[t].start));
+			local.build(tasks[t].start, tasks[t].end, tasks[t].depth);
+			sub[t].swap(local.nodes);
+			subDepth[t] = local.maxDepth;
+		});
 		// splice: subtree t's nodes go to the end, its root replaces placeholder -2 - t
 		std::vector<int32_t> rootOf(tasks.size());
+		size_t total = nodes.size();
 		for (size_t t = 0; t < tasks.size(); ++t) {
-			const int32_t off = (int32_t)nodes.size();
-			rootOf[t] = off;
-			for (BvhNode n : sub[t]) {
-				if (n.left >= 0) { n.left += off; n.right += off; }
-				nodes.push_back(n);
-			}
-			std::vector<BvhNode>().swap(sub[t]);
+			rootOf[t] = (int32_t)total;
+			total += sub[t].size();
 			if (subDepth[t] > maxDepth) maxDepth = subDepth[t];
 		}
-		for (BvhNode& n : nodes) {
+		const size_t nTop = nodes.size();
+		nodes.resize(total);
+		for (size_t i = 0; i < nTop; ++i) {
+			BvhNode& n = nodes[i];
 			if (n.left <= -2) n.left = rootOf[(size_t)(-2 - n.left)];
 			if (n.right <= -2) n.right = rootOf[(size_t)(-2 - n.right)];
 		}
+		MirtPool::get().run((uint32_t)tasks.size(), [&](uint32_t t) {
+			const int32_t off = rootOf[t];
+			BvhNode* dst = nodes.data() + off;
+			for (size_t i = 0; i < sub[t].size(); ++i) {
+				BvhNode n = sub[t][i];
+				if (n.left >= 0) { n.left += off; n.right += off; }
+				dst[i] = n;
+			}
+			std::vector<BvhNode>().swap(sub[t]);
+		});
 	}
 };

@@ -1187,6 +1187,7 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 	const unsigned long long tStart = wall_clock64();
 	unsigned long long tExhausted = 0;
 	uint32_t nRounds = 0, nLaneRounds = 0;
+	unsigned long long tRoundMax[3] = {0, 0, 0}, tRoundSum[3] = {0, 0, 0}; // camera / light / reflection rounds
 #endif
 	Walker<MODE, OVF> w;
 	// The wave works in rounds; every round is: set up to 64 rays, walk them (ONE copy of the walk in the kernel), use the
@@ -1310,6 +1311,7 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 #if MIRT_STATS || MIRT_TIMELINE
 		if (pbatch >= nBatches && !tExhausted) tExhausted = wall_clock64();
 		if (walked) { ++nRounds; nLaneRounds += (uint32_t)__popcll(walked); }
+		const unsigned long long tRound = wall_clock64();
 #endif
 		if (walked) {
 			walk_wave<false, false>(S, w, stk);
@@ -1322,6 +1324,14 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 				}
 			}
 		}
+#if MIRT_STATS || MIRT_TIMELINE
+		if (walked) {
+			const unsigned long long dt = wall_clock64() - tRound;
+			const int kind = !inBatch ? 0 : (round == ROUND_LIGHT ? 1 : 2);
+			if (dt > tRoundMax[kind]) tRoundMax[kind] = dt;
+			tRoundSum[kind] += dt;
+		}
+#endif
 		const bool hit = walk && w.best.ref != REF_NONE;
 		// ---- what the answers mean -------------------------------------------------------------------------------------
 		if (!inBatch) {
@@ -1414,6 +1424,10 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 		atomicAdd(S.dbg + 22, 1ull);
 		atomicAdd(S.dbg + 23, (unsigned long long)nRounds);
 		atomicAdd(S.dbg + 24, (unsigned long long)nLaneRounds);
+		for (int k = 0; k < 3; ++k) {
+			atomicMax(S.dbg + 25 + k, tRoundMax[k]);
+			atomicAdd(S.dbg + 28 + k, tRoundSum[k]);
+		}
 	}
 #endif
 	// statistics: a few atomics per wave
