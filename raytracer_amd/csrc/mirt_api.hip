@@ -514,6 +514,26 @@ struct Collapser {
 	}
 };
 
+// the smallest i < n with bad(i), or n: the big arrays of a description are checked on all threads, and the message
+// names the same element as a loop from the front would
+template <class F>
+uint64_t first_bad(uint64_t n, F bad) {
+	const uint32_t grain = 1u << 16;
+	const uint32_t chunks = (uint32_t)((n + grain - 1) / grain);
+	std::atomic<uint64_t> first(n);
+	MirtPool::get().run(chunks, [&](uint32_t c) {
+		const uint64_t a = (uint64_t)c * grain, b = a + grain < n ? a + grain : n;
+		if (a >= first.load(std::memory_order_relaxed)) return;
+		for (uint64_t i = a; i < b; ++i) {
+			if (!bad(i)) continue;
+			uint64_t cur = first.load();
+			while (i < cur && !first.compare_exchange_weak(cur, i)) {}
+			return;
+		}
+	});
+	return first.load();
+}
+
 int validate_desc(const mirt_scene_desc* d) {
 	if (!d) return fail(MIRT_E_INVALID, "scene description is NULL");
 	if (d->struct_size != sizeof(mirt_scene_desc)) return fail(MIRT_E_INVALID, "mirt_scene_desc.struct_size %u != %zu", d->struct_size, sizeof(mirt_scene_desc));
@@ -525,7 +545,14 @@ int validate_desc(const mirt_scene_desc* d) {
 	if (d->n_lights && !d->lights) return fail(MIRT_E_INVALID, "lights is NULL");
 	if (d->max_depth > MIRT_MAX_DEPTH_LIMIT) return fail(MIRT_E_INVALID, "max_depth %d exceeds the supported %d", d->max_depth, MIRT_MAX_DEPTH_LIMIT);
 	if (d->n_nodes >= 0x7fffffffu || d->n_leaf_prims >= 0x70000000u) return fail(MIRT_E_INVALID, "tree too large for 31-bit references");
-	for (uint32_t i = 0; i < d->n_nodes; ++i) {
+	const uint64_t badNode = first_bad(d->n_nodes, [&](uint64_t i) {
+		const mirt_node& n = d->nodes[i];
+		if (n.b & MIRT_LEAF_FLAG) return (uint64_t)n.a + (n.b & ~MIRT_LEAF_FLAG) > d->n_leaf_prims;
+		if (n.a != MIRT_NO_CHILD && (n.a <= i || n.a >= d->n_nodes)) return true;
+		if (n.b != MIRT_NO_CHILD && (n.b <= i || n.b >= d->n_nodes)) return true;
+		return n.a == MIRT_NO_CHILD && n.b == MIRT_NO_CHILD;
+	});
+	for (uint32_t i = (uint32_t)badNode; i < d->n_nodes; ++i) {
 		const mirt_node& n = d->nodes[i];
 		if (n.b & MIRT_LEAF_FLAG) {
 			const uint64_t cnt = n.b & ~MIRT_LEAF_FLAG;
@@ -538,9 +565,9 @@ int validate_desc(const mirt_scene_desc* d) {
 			if (n.a == MIRT_NO_CHILD && n.b == MIRT_NO_CHILD) return fail(MIRT_E_INVALID, "node %u: interior node without children", i);
 		}
 	}
-	for (uint32_t i = 0; i < d->n_leaf_prims; ++i)
+	for (uint32_t i = (uint32_t)first_bad(d->n_leaf_prims, [&](uint64_t k) { return d->leaf_prims[k] >= d->n_prims; }); i < d->n_leaf_prims; ++i)
 		if (d->leaf_prims[i] >= d->n_prims) return fail(MIRT_E_INVALID, "leaf_prims[%u] = %u outside the %u scene objects", i, d->leaf_prims[i], d->n_prims);
-	for (uint32_t i = 0; i < d->n_triangles; ++i)
+	for (uint32_t i = (uint32_t)first_bad(d->n_triangles, [&](uint64_t k) { return d->tri_prim[k] >= d->n_prims; }); i < d->n_triangles; ++i)
 		if (d->tri_prim[i] >= d->n_prims) return fail(MIRT_E_INVALID, "tri_prim[%u] out of range", i);
 	for (uint32_t i = 0; i < d->n_spheres; ++i)
 		if (d->sphere_prim[i] >= d->n_prims) return fail(MIRT_E_INVALID, "sphere_prim[%u] out of range", i);
@@ -554,7 +581,7 @@ int validate_desc(const mirt_scene_desc* d) {
 	}
 	// Coordinates beyond 1e18: the hierarchy's quantised child boxes (scales up to 2^73 per step of a byte) could no longer
 	// enclose a node, and squared lengths overflow a float anyway.
-	for (uint64_t i = 0; i < (uint64_t)d->n_triangles * 9; ++i)
+	for (uint64_t i = first_bad((uint64_t)d->n_triangles * 9, [&](uint64_t k) { return !(fabsf(d->tri_verts[k]) <= 1e18f); }); i < (uint64_t)d->n_triangles * 9; ++i)
 		if (!(fabsf(d->tri_verts[i]) <= 1e18f)) return fail(MIRT_E_INVALID, "triangle %llu: vertex coordinate not finite or beyond 1e18", (unsigned long long)(i / 9));
 	for (uint32_t i = 0; i < d->n_spheres; ++i) {
 		const mirt_sphere& sp = d->spheres[i];
@@ -566,7 +593,7 @@ int validate_desc(const mirt_scene_desc* d) {
 	}
 	for (int k = 0; k < 3; ++k)
 		if (!(fabsf(d->camera.look_from[k]) <= 1e18f)) return fail(MIRT_E_INVALID, "camera position not finite or beyond 1e18");
-	for (uint32_t i = 0; i < d->n_prims; ++i)
+	for (uint32_t i = (uint32_t)first_bad(d->n_prims, [&](uint64_t k) { return d->prim_material[k] >= d->n_materials; }); i < d->n_prims; ++i)
 		if (d->prim_material[i] >= d->n_materials) return fail(MIRT_E_INVALID, "prim_material[%u] out of range", i);
 	return MIRT_OK;
 }
@@ -986,13 +1013,6 @@ const char* mirt_last_error(void) { return g_err.c_str(); }
 int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	if (!out) return fail(MIRT_E_INVALID, "out is NULL");
 	*out = nullptr;
-	int e = validate_desc(d);
-	if (e) return e;
-	HIPCHK(hipSetDevice(device));
-	hipDeviceProp_t prop;
-	HIPCHK(hipGetDeviceProperties(&prop, device));
-	if ((e = scratch_init(device))) return e;
-
 	// MIRT_VERBOSE=1: seconds per phase on stderr
 	const bool verbose = getenv("MIRT_VERBOSE") != nullptr;
 	auto tPhase = std::chrono::steady_clock::now();
@@ -1002,6 +1022,9 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		fprintf(stderr, "mirt_scene_create: %-28s %.3f s\n", name, std::chrono::duration<double>(now - tPhase).count());
 		tPhase = now;
 	};
+	int e = validate_desc(d);
+	if (e) return e;
+	phase("checks of the description");
 	// Host arrays that are uploaded live until the uploads have finished: they are declared before the uploader, which
 	// copies on a thread of its own while the next arrays are being prepared.
 	std::vector<int64_t> primSlot(d->n_prims);
@@ -1013,10 +1036,9 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	mirt_scene* s = new (std::nothrow) mirt_scene();
 	if (!s) return fail(MIRT_E_NOMEM, "out of host memory");
 	s->device = device;
-	s->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	memset(&s->ds, 0, sizeof s->ds);
 	DScene& ds = s->ds;
-	Uploader up(device);
+	Uploader up(device); // (its thread is also the first to touch the device: the runtime starts up beside the work below)
 	auto bail = [&](int err) {
 		const std::string keep = g_err;
 		(void)up.finish();
@@ -1380,6 +1402,11 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	s->maxDepth = d->max_depth;
 
 	e = up.finish();
+	if (!e && hipSetDevice(device) != hipSuccess) e = fail(MIRT_E_DEVICE, "hipSetDevice(%d) failed", device);
+	hipDeviceProp_t prop;
+	if (!e && hipGetDeviceProperties(&prop, device) != hipSuccess) e = fail(MIRT_E_DEVICE, "hipGetDeviceProperties failed");
+	if (!e) s->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	if (!e) e = scratch_init(device);
 	if (!e) { e = s->dbg.ensure(32 * 8); if (!e) (void)hipMemset(s->dbg.p, 0, 32 * 8); }
 	ds.dbg = (unsigned long long*)s->dbg.p;
 	s->ovfStride = (uint32_t)s->numCUs * GRID_BLOCKS_PER_CU * BLOCK;

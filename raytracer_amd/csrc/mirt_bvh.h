@@ -16,7 +16,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <immintrin.h>
+
 #include <algorithm>
+#include <chrono>
+#include <stdio.h>
 #include <atomic>
 #include <thread>
 #include <vector>
@@ -69,17 +73,72 @@ struct BvhBuilder {
 	BvhPrim* P = nullptr; // the array build() works on
 	BvhPrim* tmp = nullptr; // as large as `prims`: the partition of a large range goes through it
 
+	// Boxes are handled four floats at a time (x, y, z and a lane that is not used).
+	typedef __m128 V4;
+	static V4 lane_mask() { return _mm_castsi128_ps(_mm_set_epi32(0, -1, -1, -1)); }
+	static V4 lo_of(const BvhPrim& p) { return _mm_and_ps(_mm_loadu_ps(p.lo), lane_mask()); }
+	static V4 hi_of(const BvhPrim& p) { return _mm_and_ps(_mm_loadu_ps(p.hi), lane_mask()); } // (the fourth float read is p.ref: masked off)
+	static float area(V4 lo, V4 hi) {
+		alignas(16) float d[4];
+		_mm_store_ps(d, _mm_sub_ps(hi, lo));
+		return 2.0f * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
+	}
+	static float area(const float* lo, const float* hi) {
+		const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+		return 2.0f * (dx * dy + dy * dz + dz * dx);
+	}
 	struct Bins {
 		uint32_t bc[3][BINS];
-		float blo[3][BINS][3], bhi[3][BINS][3];
+		V4 lo[3][BINS], hi[3][BINS];
 		void clear() {
-			for (int a = 0; a < 3; ++a) for (int b = 0; b < BINS; ++b) { bc[a][b] = 0; for (int k = 0; k < 3; ++k) { blo[a][b][k] = INFINITY; bhi[a][b][k] = -INFINITY; } }
+			const V4 pinf = _mm_set1_ps(INFINITY), ninf = _mm_set1_ps(-INFINITY);
+			for (int a = 0; a < 3; ++a) for (int b = 0; b < BINS; ++b) { bc[a][b] = 0; lo[a][b] = pinf; hi[a][b] = ninf; }
+		}
+		void add(const Bins& q) {
+			for (int a = 0; a < 3; ++a) for (int b = 0; b < BINS; ++b) {
+				bc[a][b] += q.bc[a][b];
+				lo[a][b] = _mm_min_ps(lo[a][b], q.lo[a][b]);
+				hi[a][b] = _mm_max_ps(hi[a][b], q.hi[a][b]);
+			}
 		}
 	};
-	static int bin_of(const BvhPrim& p, int ax, float clo, float scale) {
-		const float c = 0.5f * (p.lo[ax] + p.hi[ax]);
+	struct Extent {
+		V4 lo, hi, clo, chi; // bounds of the boxes and of their centres
+		bool mixed;
+		void clear() { lo = clo = _mm_set1_ps(INFINITY); hi = chi = _mm_set1_ps(-INFINITY); mixed = false; }
+	};
+	static int bin_of(float c, float clo, float scale) {
 		const int b = (int)((c - clo) * scale);
 		return b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+	}
+	static int bin_of(const BvhPrim& p, int ax, float clo, float scale) { return bin_of(0.5f * (p.lo[ax] + p.hi[ax]), clo, scale); }
+	void extent_of(uint32_t a, uint32_t b, uint32_t kind0, Extent& e) const {
+		const V4 half = _mm_set1_ps(0.5f);
+		for (uint32_t i = a; i < b; ++i) {
+			const V4 l = lo_of(P[i]), h = hi_of(P[i]);
+			const V4 c = _mm_mul_ps(half, _mm_add_ps(l, h));
+			e.lo = _mm_min_ps(e.lo, l);
+			e.hi = _mm_max_ps(e.hi, h);
+			e.clo = _mm_min_ps(e.clo, c);
+			e.chi = _mm_max_ps(e.chi, c);
+			e.mixed |= P[i].kind != kind0;
+		}
+	}
+	// all three axes in one pass; sc[ax] = bins per unit length, or 0 for an axis along which the centres do not spread
+	void bin_range(uint32_t a, uint32_t b, const float* clo, const float* sc, Bins& q) const {
+		const V4 half = _mm_set1_ps(0.5f);
+		for (uint32_t i = a; i < b; ++i) {
+			const V4 l = lo_of(P[i]), h = hi_of(P[i]);
+			alignas(16) float c[4];
+			_mm_store_ps(c, _mm_mul_ps(half, _mm_add_ps(l, h)));
+			for (int ax = 0; ax < 3; ++ax) {
+				if (!(sc[ax] > 0.0f)) continue;
+				const int bi = bin_of(c[ax], clo[ax], sc[ax]);
+				q.bc[ax][bi]++;
+				q.lo[ax][bi] = _mm_min_ps(q.lo[ax][bi], l);
+				q.hi[ax][bi] = _mm_max_ps(q.hi[ax][bi], h);
+			}
+		}
 	}
 	// stable partition of [start, end) by pred, chunk by chunk through `tmp`; returns the first index of the second part
 	template <class Pred>
@@ -109,17 +168,6 @@ struct BvhBuilder {
 		return mid;
 	}
 
-	static float area(const float* lo, const float* hi) {
-		const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-		return 2.0f * (dx * dy + dy * dz + dz * dx);
-	}
-	static void grow(float* lo, float* hi, const float* plo, const float* phi) {
-		for (int k = 0; k < 3; ++k) {
-			lo[k] = plo[k] < lo[k] ? plo[k] : lo[k];
-			hi[k] = phi[k] > hi[k] ? phi[k] : hi[k];
-		}
-	}
-
 	int32_t build(uint32_t start, uint32_t end, uint32_t depth) {
 		if (cutting && depth > 0 && end - start <= CUT) {
 			tasks.push_back(Task{start, end, depth});
@@ -128,45 +176,37 @@ struct BvhBuilder {
 		const int32_t me = (int32_t)nodes.size();
 		nodes.push_back(BvhNode());
 		if (depth > maxDepth) maxDepth = depth;
-		float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-		float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
-		bool mixed = false;
 		const bool large = tmp && end - start > CUT;
 		const uint32_t nChunks = large ? (end - start + GRAIN - 1) / GRAIN : 1u;
+		const uint32_t kind0 = P[start].kind;
+		Extent ex;
+		ex.clear();
 		if (large) {
-			struct Part { float lo[3], hi[3], clo[3], chi[3]; bool mixed; };
-			std::vector<Part> part(nChunks);
-			const uint32_t kind0 = P[start].kind;
+			std::vector<Extent> part(nChunks);
 			MirtPool::get().run(nChunks, [&](uint32_t ch) {
 				const uint32_t a = start + ch * GRAIN, b = a + GRAIN < end ? a + GRAIN : end;
-				Part q;
-				for (int k = 0; k < 3; ++k) { q.lo[k] = q.clo[k] = INFINITY; q.hi[k] = q.chi[k] = -INFINITY; }
-				q.mixed = false;
-				for (uint32_t i = a; i < b; ++i) {
-					grow(q.lo, q.hi, P[i].lo, P[i].hi);
-					float c[3];
-					for (int k = 0; k < 3; ++k) c[k] = 0.5f * (P[i].lo[k] + P[i].hi[k]);
-					grow(q.clo, q.chi, c, c);
-					q.mixed |= P[i].kind != kind0;
-				}
+				Extent q;
+				q.clear();
+				extent_of(a, b, kind0, q);
 				part[ch] = q;
 			});
-			for (const Part& q : part) { grow(lo, hi, q.lo, q.hi); grow(clo, chi, q.clo, q.chi); mixed |= q.mixed; }
+			for (const Extent& q : part) {
+				ex.lo = _mm_min_ps(ex.lo, q.lo); ex.hi = _mm_max_ps(ex.hi, q.hi);
+				ex.clo = _mm_min_ps(ex.clo, q.clo); ex.chi = _mm_max_ps(ex.chi, q.chi);
+				ex.mixed |= q.mixed;
+			}
 		}
-		else for (uint32_t i = start; i < end; ++i) {
-			grow(lo, hi, P[i].lo, P[i].hi);
-			float c[3];
-			for (int k = 0; k < 3; ++k) c[k] = 0.5f * (P[i].lo[k] + P[i].hi[k]);
-			grow(clo, chi, c, c);
-			mixed |= P[i].kind != P[start].kind;
-		}
+		else extent_of(start, end, kind0, ex);
+		const bool mixed = ex.mixed;
+		alignas(16) float lo[4], hi[4], clo[4], chi[4];
+		_mm_store_ps(lo, ex.lo); _mm_store_ps(hi, ex.hi); _mm_store_ps(clo, ex.clo); _mm_store_ps(chi, ex.chi);
 		BvhNode n;
 		memcpy(n.lo, lo, 12);
 		memcpy(n.hi, hi, 12);
 		n.left = n.right = -1;
 		n.first = start;
 		n.count = end - start;
-		n.kind = P[start].kind;
+		n.kind = kind0;
 		const uint32_t cnt = end - start;
 		if (cnt <= LEAF_MIN && !mixed) { nodes[me] = n; return me; }
 
@@ -182,72 +222,44 @@ struct BvhBuilder {
 			for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > ext) { ext = chi[k] - clo[k]; axis = k; }
 			bool done = false;
 			if (ext > 0.0f && depth < (uint32_t)SAH_DEPTH) {
-				float bestCost = INFINITY, bestScale = 0.0f;
-				int bestBin = -1, bestAxis = -1;
-				// a large range is binned along all three axes in one pass over its chunks
-				Bins* all = nullptr;
-				std::vector<Bins> partBins;
-				Bins total;
+				float sc[3];
+				for (int ax = 0; ax < 3; ++ax) sc[ax] = chi[ax] - clo[ax] > 0.0f ? (float)BINS / (chi[ax] - clo[ax]) : 0.0f;
+				Bins bins;
+				bins.clear();
 				if (large) {
-					partBins.resize(nChunks);
-					float sc[3];
-					for (int ax = 0; ax < 3; ++ax) sc[ax] = chi[ax] - clo[ax] > 0.0f ? (float)BINS / (chi[ax] - clo[ax]) : 0.0f;
+					std::vector<Bins> part(nChunks);
 					MirtPool::get().run(nChunks, [&](uint32_t ch) {
 						const uint32_t a = start + ch * GRAIN, b = a + GRAIN < end ? a + GRAIN : end;
-						Bins& q = partBins[ch];
-						q.clear();
-						for (uint32_t i = a; i < b; ++i) {
-							for (int ax = 0; ax < 3; ++ax) {
-								if (!(sc[ax] > 0.0f)) continue;
-								const int bi = bin_of(P[i], ax, clo[ax], sc[ax]);
-								q.bc[ax][bi]++;
-								grow(q.blo[ax][bi], q.bhi[ax][bi], P[i].lo, P[i].hi);
-							}
-						}
+						part[ch].clear();
+						bin_range(a, b, clo, sc, part[ch]);
 					});
-					total.clear();
-					for (const Bins& q : partBins)
-						for (int ax = 0; ax < 3; ++ax) for (int b = 0; b < BINS; ++b) {
-							total.bc[ax][b] += q.bc[ax][b];
-							grow(total.blo[ax][b], total.bhi[ax][b], q.blo[ax][b], q.bhi[ax][b]);
-						}
-					all = &total;
+					for (const Bins& q : part) bins.add(q);
 				}
+				else bin_range(start, end, clo, sc, bins);
+				float bestCost = INFINITY, bestScale = 0.0f;
+				int bestBin = -1, bestAxis = -1;
+				const V4 pinf = _mm_set1_ps(INFINITY), ninf = _mm_set1_ps(-INFINITY);
 				for (int ax = 0; ax < 3; ++ax) {
-					const float e = chi[ax] - clo[ax];
-					if (!(e > 0.0f)) continue;
-					uint32_t bcLocal[BINS] = {0};
-					float bloLocal[BINS][3], bhiLocal[BINS][3];
-					const float scale = (float)BINS / e;
-					if (!all) {
-						for (int b = 0; b < BINS; ++b) for (int k = 0; k < 3; ++k) { bloLocal[b][k] = INFINITY; bhiLocal[b][k] = -INFINITY; }
-						for (uint32_t i = start; i < end; ++i) {
-							const int b = bin_of(P[i], ax, clo[ax], scale);
-							bcLocal[b]++;
-							grow(bloLocal[b], bhiLocal[b], P[i].lo, P[i].hi);
-						}
-					}
-					const uint32_t* bc = all ? all->bc[ax] : bcLocal;
-					const float (*blo)[3] = all ? all->blo[ax] : bloLocal;
-					const float (*bhi)[3] = all ? all->bhi[ax] : bhiLocal;
+					if (!(sc[ax] > 0.0f)) continue;
+					const uint32_t* bc = bins.bc[ax];
 					float rightArea[BINS];
 					uint32_t rightCnt[BINS];
-					float rlo[3] = {INFINITY, INFINITY, INFINITY}, rhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+					V4 rlo = pinf, rhi = ninf;
 					uint32_t rc = 0;
 					for (int b = BINS - 1; b > 0; --b) {
-						if (bc[b]) grow(rlo, rhi, blo[b], bhi[b]);
+						if (bc[b]) { rlo = _mm_min_ps(rlo, bins.lo[ax][b]); rhi = _mm_max_ps(rhi, bins.hi[ax][b]); }
 						rc += bc[b];
 						rightArea[b] = rc ? area(rlo, rhi) : 0.0f;
 						rightCnt[b] = rc;
 					}
-					float llo[3] = {INFINITY, INFINITY, INFINITY}, lhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+					V4 llo = pinf, lhi = ninf;
 					uint32_t lc = 0;
 					for (int b = 0; b < BINS - 1; ++b) {
-						if (bc[b]) grow(llo, lhi, blo[b], bhi[b]);
+						if (bc[b]) { llo = _mm_min_ps(llo, bins.lo[ax][b]); lhi = _mm_max_ps(lhi, bins.hi[ax][b]); }
 						lc += bc[b];
 						if (lc == 0 || rightCnt[b + 1] == 0) continue;
 						const float cost = area(llo, lhi) * (float)lc + rightArea[b + 1] * (float)rightCnt[b + 1];
-						if (cost < bestCost) { bestCost = cost; bestBin = b; bestAxis = ax; bestScale = scale; }
+						if (cost < bestCost) { bestCost = cost; bestBin = b; bestAxis = ax; bestScale = sc[ax]; }
 					}
 				}
 				if (bestBin >= 0) {
@@ -293,7 +305,9 @@ struct BvhBuilder {
 		std::vector<BvhPrim> scratch;
 		if (cutting) scratch.resize(prims.size());
 		tmp = cutting ? scratch.data() : nullptr;
+		const auto t0 = std::chrono::steady_clock::now();
 		build(0, (uint32_t)prims.size(), 0);
+		const auto t1 = std::chrono::steady_clock::now();
 		cutting = false;
 		tmp = nullptr;
 		std::vector<BvhPrim>().swap(scratch);
@@ -310,6 +324,7 @@ struct BvhBuilder {
 			sub[t].swap(local.nodes);
 			subDepth[t] = local.maxDepth;
 		});
+		const auto t2 = std::chrono::steady_clock::now();
 		// splice: subtree t's nodes go to the end, its root replaces placeholder -2 - t
 		std::vector<int32_t> rootOf(tasks.size());
 		size_t total = nodes.size();
@@ -335,5 +350,6 @@ struct BvhBuilder {
 			}
 			std::vector<BvhNode>().swap(sub[t]);
 		});
+		if (getenv("MIRT_VERBOSE")) fprintf(stderr, "  bvh: top %.3f tasks %.3f (%zu) splice %.3f\n", std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count(), tasks.size(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count());
 	}
 };
