@@ -1170,6 +1170,10 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 	// instead of sitting on a long queue of its own).  A wave's first batch is its own; later ones come from CTR_F_NCUR
 	// counters that hand out the batch numbers in turn -- one address sustains only ~88 atomics per microsecond, a 4K frame has
 	// 130 000 batches.  A wave starts at one counter and moves on to the next when that one has run out.
+	// (Measured and dropped: giving the waves of one XCD -- one L2 -- a band of the image of their own, by the block's
+	// place in the dispatcher's round or by the hardware's XCD number, instead of every eighth batch.  The L2 hit rate of a
+	// Stanford dragon frame rises from 0.69 to 0.74 and the HBM traffic falls by 18 %, the frame rate does not move, a
+	// frame alone ends 3 % later, and a 10-million-triangle scene loses 8 %.)
 	const uint32_t nWaves = gridDim.x * (FRAME_BLOCK / WAVE);
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (FRAME_BLOCK / WAVE) + (threadIdx.x >> 6));
 	const uint32_t nBatches = (F.nSlots + 63u) >> 6;
