@@ -4,6 +4,7 @@
 // results (combined in chunk order) do not either.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <atomic>
 #include <condition_variable>
@@ -87,6 +88,7 @@ private:
 	MirtPool() {
 		unsigned n = std::thread::hardware_concurrency();
 		n = n > 16 ? 16 : (n < 1 ? 1 : n);
+		if (const char* e = getenv("MIRT_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) n = (unsigned)v; } // 1: everything on the calling thread
 		for (unsigned i = 1; i < n; ++i) th_.emplace_back([this]() { loop(); });
 	}
 	~MirtPool() {
