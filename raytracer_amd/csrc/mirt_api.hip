@@ -10,6 +10,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -1462,12 +1466,12 @@ void mirt_scene_destroy(mirt_scene* s) {
 // (pointers meaningless), SceneMeta, then for each of the eleven device arrays a 64-bit byte count and the bytes.
 namespace {
 const char SCENE_MAGIC[8] = {'M', 'I', 'R', 'T', 'S', 'C', 'N', '1'};
-const uint32_t SCENE_VERSION = 2;
+const uint32_t SCENE_VERSION = 3;
 struct SceneHeader {
 	char magic[8];
 	uint32_t version, dsceneBytes, metaBytes, pad;
 	uint32_t user[4];
-	uint64_t checksum; // FNV-1a over everything after the header
+	uint64_t checksum; // sum_of() chained over everything after the header, piece by piece as written
 };
 struct SceneMeta {
 	uint32_t nested, bvhDepth, deepBvh, nLights;
@@ -1482,6 +1486,19 @@ inline uint64_t fnv1a(uint64_t h, const void* p, size_t n) {
 	for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, b + i, 8); h = (h ^ w) * 0x100000001b3ull; }
 	for (; i < n; ++i) h = (h ^ b[i]) * 0x100000001b3ull;
 	return h;
+}
+// The checksum of one piece of the file, chained onto h: FNV-1a of the piece if it is small, otherwise FNV-1a of the
+// FNV-1a digests of its 1-MiB blocks, which are taken on all threads (the result does not depend on their number).
+inline uint64_t sum_of(uint64_t h, const void* p, size_t n) {
+	const size_t blk = (size_t)1 << 20;
+	if (n <= blk) return fnv1a(h, p, n);
+	const uint32_t blocks = (uint32_t)((n + blk - 1) / blk);
+	std::vector<uint64_t> dig(blocks);
+	MirtPool::get().run(blocks, [&](uint32_t b) {
+		const size_t a = (size_t)b * blk, len = a + blk < n ? blk : n - a;
+		dig[b] = fnv1a(0xcbf29ce484222325ull, (const uint8_t*)p + a, len);
+	});
+	return fnv1a(h, dig.data(), (size_t)blocks * 8);
 }
 DevBuf* scene_buffers(mirt_scene* s, int k) {
 	DevBuf* const all[11] = {&s->nodes, &s->leafs, &s->bvh, &s->memb, &s->tris, &s->triX, &s->triInfo, &s->spheres, &s->sphInfo, &s->materials, &s->lights};
@@ -1524,17 +1541,17 @@ int mirt_scene_save(mirt_scene* s, const char* path, const uint32_t user[4]) {
 	memcpy(m.diag, s->diag, sizeof m.diag);
 	bool ok = fwrite(&h, sizeof h, 1, f) == 1;
 	uint64_t sum = 0xcbf29ce484222325ull;
-	auto put = [&](const void* p, size_t n) { sum = fnv1a(sum, p, n); ok = ok && (n == 0 || fwrite(p, n, 1, f) == 1); };
+	auto put = [&](const void* p, size_t n) { sum = sum_of(sum, p, n); ok = ok && (n == 0 || fwrite(p, n, 1, f) == 1); };
 	put(&s->ds, sizeof s->ds);
 	put(&m, sizeof m);
-	std::vector<uint8_t> tmp;
+	HostBuf<uint8_t> tmp;
 	for (int k = 0; k < 11 && ok; ++k) {
 		DevBuf* b = scene_buffers(s, k);
 		const uint64_t n = b->bytes;
 		put(&n, 8);
-		tmp.resize(n);
-		if (n && hipMemcpy(tmp.data(), b->p, n, hipMemcpyDeviceToHost) != hipSuccess) { fclose(f); return fail(MIRT_E_DEVICE, "mirt_scene_save: copy from the device failed"); }
-		put(tmp.data(), n);
+		if (!tmp.alloc(n)) { fclose(f); return fail(MIRT_E_NOMEM, "out of host memory"); }
+		if (n && hipMemcpy(tmp.p, b->p, n, hipMemcpyDeviceToHost) != hipSuccess) { fclose(f); return fail(MIRT_E_DEVICE, "mirt_scene_save: copy from the device failed"); }
+		put(tmp.p, n);
 	}
 	h.checksum = sum;
 	ok = ok && fseek(f, 0, SEEK_SET) == 0 && fwrite(&h, sizeof h, 1, f) == 1;
@@ -1546,45 +1563,89 @@ int mirt_scene_save(mirt_scene* s, const char* path, const uint32_t user[4]) {
 int mirt_scene_load(const char* path, int device, mirt_scene** out, uint32_t user_out[4]) {
 	if (!path || !out) return fail(MIRT_E_INVALID, "NULL argument");
 	*out = nullptr;
-	FILE* f = fopen(path, "rb");
-	if (!f) return fail(MIRT_E_INVALID, "cannot open %s", path);
+	// The file is mapped, not read: the arrays go to the device straight from the mapping on the uploader's thread while
+	// the pool's threads take the checksum of the same pages.
+	struct Mapping {
+		int fd = -1;
+		const uint8_t* p = nullptr;
+		size_t n = 0;
+		~Mapping() {
+			if (p) munmap((void*)p, n);
+			if (fd >= 0) close(fd);
+		}
+	} map;
+	map.fd = open(path, O_RDONLY);
+	if (map.fd < 0) return fail(MIRT_E_INVALID, "cannot open %s", path);
+	struct stat sb;
+	if (fstat(map.fd, &sb) != 0 || (size_t)sb.st_size < sizeof(SceneHeader)) return fail(MIRT_E_INVALID, "%s is not a scene cache file", path);
+	map.n = (size_t)sb.st_size;
+	void* mp = mmap(nullptr, map.n, PROT_READ, MAP_PRIVATE, map.fd, 0);
+	if (mp == MAP_FAILED) return fail(MIRT_E_INVALID, "cannot map %s", path);
+	map.p = (const uint8_t*)mp;
 	SceneHeader h;
-	if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, SCENE_MAGIC, 8) != 0) { fclose(f); return fail(MIRT_E_INVALID, "%s is not a scene cache file", path); }
-	if (h.version != SCENE_VERSION || h.dsceneBytes != sizeof(DScene) || h.metaBytes != sizeof(SceneMeta)) {
-		fclose(f);
+	memcpy(&h, map.p, sizeof h);
+	if (memcmp(h.magic, SCENE_MAGIC, 8) != 0) return fail(MIRT_E_INVALID, "%s is not a scene cache file", path);
+	if (h.version != SCENE_VERSION || h.dsceneBytes != sizeof(DScene) || h.metaBytes != sizeof(SceneMeta))
 		return fail(MIRT_E_INVALID, "%s was written by another version of the library (format %u, this library reads %u): build the scene again", path, h.version, SCENE_VERSION);
-	}
-	hipError_t he = hipSetDevice(device);
-	hipDeviceProp_t prop;
-	if (he == hipSuccess) he = hipGetDeviceProperties(&prop, device);
-	if (he != hipSuccess) { fclose(f); return fail(MIRT_E_DEVICE, "device %d: %s", device, hipGetErrorString(he)); }
-	int e = scratch_init(device);
-	if (e) { fclose(f); return e; }
 	mirt_scene* s = new (std::nothrow) mirt_scene();
-	if (!s) { fclose(f); return fail(MIRT_E_NOMEM, "out of host memory"); }
+	if (!s) return fail(MIRT_E_NOMEM, "out of host memory");
 	s->device = device;
-	s->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	SceneMeta m;
+	memset(&m, 0, sizeof m);
 	uint64_t sum = 0xcbf29ce484222325ull;
-	bool ok = fread(&s->ds, sizeof s->ds, 1, f) == 1 && fread(&m, sizeof m, 1, f) == 1;
-	if (ok) { sum = fnv1a(sum, &s->ds, sizeof s->ds); sum = fnv1a(sum, &m, sizeof m); }
+	size_t at = sizeof h;
 	const char* why = "truncated file";
-	std::vector<uint8_t> tmp;
-	static const uint32_t recordBytes[11] = {64, 4, 64, 32, 64, 32, 16, 144, 16, 64, 32};
-	for (int k = 0; k < 11 && ok; ++k) {
-		uint64_t n = 0;
-		ok = fread(&n, 8, 1, f) == 1;
-		if (!ok) break;
-		sum = fnv1a(sum, &n, 8);
-		if (n > (1ull << 40) || (n % recordBytes[k] != 0 && n != 16)) { ok = false; why = "array size not a whole number of records"; break; }
-		try { tmp.resize(n); } catch (...) { ok = false; why = "out of host memory"; break; }
-		if (n && fread(tmp.data(), n, 1, f) != 1) { ok = false; break; }
-		sum = fnv1a(sum, tmp.data(), n);
-		if (upload(*scene_buffers(s, k), tmp.data(), n)) { ok = false; why = "device allocation or copy failed"; break; }
+	bool ok = map.n - at >= sizeof s->ds + sizeof m;
+	int devErr = MIRT_OK;
+	std::string devMsg;
+	{
+		Uploader up(device); // (also the first to touch the device: the runtime starts up beside the checksum)
+		if (ok) {
+			memcpy(&s->ds, map.p + at, sizeof s->ds);
+			sum = sum_of(sum, map.p + at, sizeof s->ds);
+			at += sizeof s->ds;
+			memcpy(&m, map.p + at, sizeof m);
+			sum = sum_of(sum, map.p + at, sizeof m);
+			at += sizeof m;
+		}
+		static const uint32_t recordBytes[11] = {64, 4, 64, 32, 64, 32, 16, 144, 16, 64, 32};
+		for (int k = 0; k < 11 && ok; ++k) {
+			uint64_t n = 0;
+			if (map.n - at < 8) { ok = false; break; }
+			memcpy(&n, map.p + at, 8);
+			sum = sum_of(sum, map.p + at, 8);
+			at += 8;
+			if (n > (1ull << 40) || (n % recordBytes[k] != 0 && n != 16)) { ok = false; why = "array size not a whole number of records"; break; }
+			if (map.n - at < n) { ok = false; break; }
+			up.push(*scene_buffers(s, k), map.p + at, n);
+			sum = sum_of(sum, map.p + at, n);
+			at += n;
+		}
+		devErr = up.finish();
+		if (devErr) devMsg = g_err;
 	}
-	fclose(f);
 	if (ok && sum != h.checksum) { ok = false; why = "checksum mismatch (file damaged)"; }
 	if (ok && (m.maxDepth > MIRT_MAX_DEPTH_LIMIT || m.nLights != s->ds.nLights || s->lights.bytes < (size_t)m.nLights * 32)) { ok = false; why = "inconsistent header"; }
+	if (ok && devErr) {
+		mirt_scene_destroy(s);
+		g_err = devMsg;
+		return devErr;
+	}
+	hipDeviceProp_t prop;
+	if (ok && (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess)) {
+		mirt_scene_destroy(s);
+		return fail(MIRT_E_DEVICE, "device %d: no properties", device);
+	}
+	if (ok) {
+		s->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+		const int e = scratch_init(device);
+		if (e) {
+			const std::string keep = g_err;
+			mirt_scene_destroy(s);
+			g_err = keep;
+			return e;
+		}
+	}
 	if (ok && (s->dbg.ensure(32 * 8) || hipMemset(s->dbg.p, 0, 32 * 8) != hipSuccess)) { ok = false; why = "device allocation failed"; }
 	if (!ok) {
 		mirt_scene_destroy(s);
