@@ -24,7 +24,8 @@ typedef struct mirt_host_scene mirt_host_scene;
  * Scene.cpp:15-224.  Where the reference has undefined behaviour (vertex index outside `maxverts`, `vertex` before
  * `maxverts`, no `size` line) this returns MIRT_E_INVALID instead; lines the reference skips with a message
  * (unknown command, unreadable value: Scene.cpp:204-206, 235-244) are skipped silently here too.
- * threads: worker threads for the tree build, 0 = number of CPUs (at most 16). */
+ * threads: 1 = the tree is built on the calling thread alone; any other value = on the library's thread pool (one
+ * thread per CPU, at most 16; MIRT_THREADS in the environment sets another number).  The tree is the same either way. */
 int mirt_host_scene_load(const char* path, uint32_t threads, mirt_host_scene** out);
 
 /* The same from memory (text need not be NUL-terminated). */

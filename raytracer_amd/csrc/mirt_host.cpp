@@ -20,6 +20,7 @@
 
 #include "../../include/mirt_host.h"
 #include "mirt_internal.h"
+#include "mirt_pool.h"
 
 namespace {
 
@@ -294,11 +295,15 @@ struct PNode {
 	PNode* right = nullptr;
 	std::vector<uint32_t> objs; // PartitionNode::objects, insertion order; released once the node has been split
 	bool leaf = true;
+	int32_t task = -1;          // the subtree below this node is built, flattened and freed as task number `task`
 };
 
+// The top of the tree -- nodes holding more than TASK_OBJS objects -- is split node by node, each node's objects
+// classified and handed to the children on all threads (fixed chunks, children's lists filled in chunk order, so the
+// lists are in insertion order whatever the thread count).  A node at or below TASK_OBJS is not split there: the whole
+// subtree under it is one task for the thread pool, built by one thread's recursion.
 struct Builder {
 	const Prims& P;
-	std::atomic<int> spare; // worker threads not in use
 	std::atomic<bool> oom;
 	// Partition::split (Partition.cpp:77-101) does not always terminate.  When a box is one float step wide on its longest
 	// axis, "max - (max - min) / 2" rounds to one of its ends, so one child gets the parent's own box (and with it the
@@ -309,18 +314,12 @@ struct Builder {
 	// and with the triangle count -- a 10 x 10 grid of Stanford dragons has such vertices, one dragon does not.
 	// Here the repeating child is kept as a leaf and counted; everything above it is the reference's tree.
 	std::atomic<uint64_t> truncated;
-	Builder(const Prims& p, int threads) : P(p), spare(threads - 1), oom(false), truncated(0) {}
-
-	int grab(int want) {
-		int got = 0;
-		while (got < want) {
-			int s = spare.load();
-			if (s <= 0) break;
-			if (spare.compare_exchange_weak(s, s - 1)) ++got;
-		}
-		return got;
-	}
-	void give(int n) { spare.fetch_add(n); }
+	static const size_t TASK_OBJS = 1u << 15;
+	static const uint32_t GRAIN = 1u << 12;
+	struct Task { PNode* node; int prevMatches; uint64_t nodes, refs, nodeBase, refBase; };
+	std::vector<Task> tasks;
+	bool serial; // one thread asked for: no pool, no tasks
+	Builder(const Prims& p, int threads) : P(p), oom(false), truncated(0), serial(threads <= 1) {}
 
 	// AABB::getLongestAxis / getMidPoint / splitLeft / splitRight, AABB.cpp:106-155
 	static void split_boxes(const Box& b, Box& l, Box& r) {
@@ -335,25 +334,61 @@ struct Builder {
 		else { l.hi.z = mid.z; r.lo.z = mid.z; }
 	}
 
-	// which of the node's objects each child box contains: bit 0 = left, bit 1 = right (Partition.cpp:82-88)
-	void classify(const std::vector<uint32_t>& objs, const Box& lb, const Box& rb, uint8_t* side) {
+	// which of the objects each box contains: bit 0 = lb, bit 1 = rb (Partition.cpp:82-88)
+	void classify(const uint32_t* objs, size_t n, const Box& lb, const Box& rb, uint8_t* side) const {
+		for (size_t i = 0; i < n; ++i) side[i] = (uint8_t)((box_contains(P, lb, objs[i]) ? 1 : 0) | (box_contains(P, rb, objs[i]) ? 2 : 0));
+	}
+	// the children's object lists (insertion order kept) and the number of objects in both; returns that number
+	int distribute(const std::vector<uint32_t>& objs, const Box& lb, const Box& rb, std::vector<uint32_t>& lo, std::vector<uint32_t>& ro, bool top) const {
 		const size_t n = objs.size();
-		auto work = [&](size_t b, size_t e) {
-			for (size_t i = b; i < e; ++i) side[i] = (uint8_t)((box_contains(P, lb, objs[i]) ? 1 : 0) | (box_contains(P, rb, objs[i]) ? 2 : 0));
-		};
-		int extra = n >= 65536 ? grab((int)(n / 32768 > 64 ? 64 : n / 32768)) : 0;
-		if (extra == 0) { work(0, n); return; }
-		std::vector<std::thread> th;
-		const size_t parts = (size_t)extra + 1, per = (n + parts - 1) / parts;
-		for (int t = 0; t < extra; ++t) th.emplace_back(work, per * (t + 1) < n ? per * (t + 1) : n, per * (t + 2) < n ? per * (t + 2) : n);
-		work(0, per < n ? per : n);
-		for (auto& t : th) t.join();
-		give(extra);
+		std::vector<uint8_t> side(n);
+		if (!top || n <= TASK_OBJS) {
+			classify(objs.data(), n, lb, rb, side.data());
+			size_t nl = 0, nr = 0;
+			for (size_t i = 0; i < n; ++i) { nl += side[i] & 1; nr += side[i] >> 1; }
+			lo.reserve(nl);
+			ro.reserve(nr);
+			int matches = 0;
+			for (size_t i = 0; i < n; ++i) {
+				if (side[i] & 1) lo.push_back(objs[i]);
+				if (side[i] & 2) ro.push_back(objs[i]);
+				if (side[i] == 3) ++matches;
+			}
+			return matches;
+		}
+		const uint32_t chunks = (uint32_t)((n + GRAIN - 1) / GRAIN);
+		struct Cnt { size_t l, r, m; };
+		std::vector<Cnt> cnt((size_t)chunks + 1, Cnt{0, 0, 0});
+		MirtPool::get().run(chunks, [&](uint32_t c) {
+			const size_t a = (size_t)c * GRAIN, b = a + GRAIN < n ? a + GRAIN : n;
+			classify(objs.data() + a, b - a, lb, rb, side.data() + a);
+			Cnt k = {0, 0, 0};
+			for (size_t i = a; i < b; ++i) { k.l += side[i] & 1; k.r += side[i] >> 1; k.m += side[i] == 3 ? 1u : 0u; }
+			cnt[c + 1] = k;
+		});
+		for (uint32_t c = 0; c < chunks; ++c) { cnt[c + 1].l += cnt[c].l; cnt[c + 1].r += cnt[c].r; cnt[c + 1].m += cnt[c].m; }
+		lo.resize(cnt[chunks].l);
+		ro.resize(cnt[chunks].r);
+		MirtPool::get().run(chunks, [&](uint32_t c) {
+			const size_t a = (size_t)c * GRAIN, b = a + GRAIN < n ? a + GRAIN : n;
+			uint32_t* pl = lo.data() + cnt[c].l;
+			uint32_t* pr = ro.data() + cnt[c].r;
+			for (size_t i = a; i < b; ++i) {
+				if (side[i] & 1) *pl++ = objs[i];
+				if (side[i] & 2) *pr++ = objs[i];
+			}
+		});
+		return (int)cnt[chunks].m;
 	}
 
-	// Partition::split, Partition.cpp:77-101
-	void split(PNode* node, int prevMatches) {
-		if (node == nullptr || oom.load()) return;
+	// Partition::split, Partition.cpp:77-101.  top: on the calling thread near the root (subtrees become tasks)
+	void split(PNode* node, int prevMatches, bool top) {
+		if (node == nullptr || oom.load(std::memory_order_relaxed)) return;
+		if (top && !serial && node->objs.size() <= TASK_OBJS) {
+			node->task = (int32_t)tasks.size();
+			tasks.push_back(Task{node, prevMatches, 0, 0, 0, 0});
+			return;
+		}
 		if (!(((float)prevMatches / (float)node->objs.size()) < 0.5f)) return; // 0/0 is NaN: an empty node is never split
 		Box lb, rb;
 		split_boxes(node->box, lb, rb);
@@ -364,18 +399,7 @@ struct Builder {
 			r = new PNode();
 			l->box = lb;
 			r->box = rb;
-			const size_t n = node->objs.size();
-			std::vector<uint8_t> side(n);
-			classify(node->objs, lb, rb, side.data());
-			size_t nl = 0, nr = 0;
-			for (size_t i = 0; i < n; ++i) { nl += side[i] & 1; nr += side[i] >> 1; }
-			l->objs.reserve(nl);
-			r->objs.reserve(nr);
-			for (size_t i = 0; i < n; ++i) {
-				if (side[i] & 1) l->objs.push_back(node->objs[i]);
-				if (side[i] & 2) r->objs.push_back(node->objs[i]);
-				if (side[i] == 3) ++matches;
-			}
+			matches = distribute(node->objs, lb, rb, l->objs, r->objs, top && !serial);
 		} catch (const std::bad_alloc&) {
 			delete l;
 			delete r;
@@ -395,33 +419,46 @@ struct Builder {
 			const bool sameL = l && memcmp(&l->box, &node->box, sizeof(Box)) == 0, sameR = r && memcmp(&r->box, &node->box, sizeof(Box)) == 0;
 			if (sameL || sameR) {
 				truncated.fetch_add(1);
-				if (!sameL) split(l, matches);
-				if (!sameR) split(r, matches);
+				if (!sameL) split(l, matches, top);
+				if (!sameR) split(r, matches, top);
 				return;
 			}
 		}
-		if (l && r && l->objs.size() >= 4096 && r->objs.size() >= 4096 && grab(1) == 1) {
-			std::thread t([this, l, matches]() { split(l, matches); });
-			split(r, matches);
-			t.join();
-			give(1);
-		}
-		else {
-			split(l, matches);
-			split(r, matches);
-		}
+		split(l, matches, top);
+		split(r, matches, top);
+	}
+
+	// the subtrees left to the pool, each by one thread; afterwards every task knows the size of its subtree
+	void run_tasks() {
+		MirtPool::get().run((uint32_t)tasks.size(), [&](uint32_t t) {
+			Task& k = tasks[t];
+			try {
+				split(k.node, k.prevMatches, false);
+				std::vector<const PNode*> st(1, k.node);
+				while (!st.empty()) {
+					const PNode* x = st.back();
+					st.pop_back();
+					++k.nodes;
+					if (x->leaf) k.refs += x->objs.size();
+					if (x->left) st.push_back(x->left);
+					if (x->right) st.push_back(x->right);
+				}
+			} catch (const std::bad_alloc&) {
+				oom.store(true);
+			}
+		});
 	}
 };
 
-void free_tree(PNode* n) {
-	// iterative: single-child chains can be long
+// the nodes of a subtree; explicit stack: single-child chains can be long.  Children that are tasks are left alone.
+void free_tree(PNode* n, bool skipTasks = false) {
 	std::vector<PNode*> st;
 	if (n) st.push_back(n);
 	while (!st.empty()) {
 		PNode* x = st.back();
 		st.pop_back();
-		if (x->left) st.push_back(x->left);
-		if (x->right) st.push_back(x->right);
+		if (x->left && !(skipTasks && x->left->task >= 0)) st.push_back(x->left);
+		if (x->right && !(skipTasks && x->right->task >= 0)) st.push_back(x->right);
 		delete x;
 	}
 }
@@ -451,36 +488,29 @@ struct mirt_host_scene {
 
 namespace {
 
-struct FlatCount { uint64_t nodes, refs; };
-
-// depth-first pre-order, left first; explicit stack (chains of single children make the tree deep)
-int flatten(PNode* root, mirt_host_scene& S) {
-	uint64_t nNodes = 0, nRefs = 0;
-	{
-		std::vector<PNode*> st(1, root);
-		while (!st.empty()) {
-			PNode* x = st.back();
-			st.pop_back();
-			++nNodes;
-			if (x->leaf) nRefs += x->objs.size();
-			if (x->left) st.push_back(x->left);
-			if (x->right) st.push_back(x->right);
-		}
-	}
-	if (nNodes >= MIRT_NO_CHILD || nRefs >= 0x7fffffffull) return mirt_set_error(MIRT_E_INVALID, "Partition tree too large for 31-bit indices: %llu nodes, %llu leaf entries", (unsigned long long)nNodes, (unsigned long long)nRefs);
-	S.nodes.resize(nNodes);
-	S.leafPrims.resize(nRefs);
-	uint64_t nextNode = 0, nextRef = 0;
-	// work items: a node to emit, plus where its index has to be written (parent's a or b field)
+// One subtree in depth-first pre-order, left first, into S.nodes from index nextNode and S.leafPrims from nextRef; explicit
+// stack (chains of single children make the tree deep).  parent/side: where the subtree root's index is written (-1: nowhere).
+// With `tasks`, a node that is a task's root is not descended into: its place is reserved (the task's sizes are known),
+// its index written to its parent, and the task flattens its own subtree later.
+void flatten_subtree(PNode* root, mirt_host_scene& S, uint64_t nextNode, uint64_t nextRef, uint32_t parent, int side, std::vector<Builder::Task>* tasks) {
 	struct Item { PNode* n; uint32_t parent; int side; };
 	std::vector<Item> st;
-	st.push_back(Item{ root, 0, -1 });
+	st.push_back(Item{ root, parent, side });
 	while (!st.empty()) {
 		const Item it = st.back();
 		st.pop_back();
-		const uint32_t me = (uint32_t)nextNode++;
+		const uint32_t me = (uint32_t)nextNode;
 		if (it.side == 0) S.nodes[it.parent].a = me;
 		else if (it.side == 1) S.nodes[it.parent].b = me;
+		if (tasks && it.n->task >= 0) {
+			Builder::Task& k = (*tasks)[(size_t)it.n->task];
+			k.nodeBase = nextNode;
+			k.refBase = nextRef;
+			nextNode += k.nodes;
+			nextRef += k.refs;
+			continue;
+		}
+		++nextNode;
 		mirt_node& rec = S.nodes[me];
 		rec.bmin[0] = it.n->box.lo.x; rec.bmin[1] = it.n->box.lo.y; rec.bmin[2] = it.n->box.lo.z;
 		rec.bmax[0] = it.n->box.hi.x; rec.bmax[1] = it.n->box.hi.y; rec.bmax[2] = it.n->box.hi.z;
@@ -496,10 +526,36 @@ int flatten(PNode* root, mirt_host_scene& S) {
 			if (it.n->left) st.push_back(Item{ it.n->left, me, 0 });
 		}
 	}
+}
+
+int flatten(PNode* root, mirt_host_scene& S, Builder& B) {
+	// sizes: the tasks know theirs, the top is counted here
+	uint64_t nNodes = 0, nRefs = 0;
+	{
+		std::vector<PNode*> st(1, root);
+		while (!st.empty()) {
+			PNode* x = st.back();
+			st.pop_back();
+			if (x->task >= 0) { nNodes += B.tasks[(size_t)x->task].nodes; nRefs += B.tasks[(size_t)x->task].refs; continue; }
+			++nNodes;
+			if (x->leaf) nRefs += x->objs.size();
+			if (x->left) st.push_back(x->left);
+			if (x->right) st.push_back(x->right);
+		}
+	}
+	if (nNodes >= MIRT_NO_CHILD || nRefs >= 0x7fffffffull) return mirt_set_error(MIRT_E_INVALID, "Partition tree too large for 31-bit indices: %llu nodes, %llu leaf entries", (unsigned long long)nNodes, (unsigned long long)nRefs);
+	S.nodes.resize(nNodes);
+	S.leafPrims.resize(nRefs);
+	flatten_subtree(root, S, 0, 0, 0, -1, &B.tasks);
+	MirtPool::get().run((uint32_t)B.tasks.size(), [&](uint32_t t) {
+		const Builder::Task& k = B.tasks[t];
+		flatten_subtree(k.node, S, k.nodeBase, k.refBase, 0, -1, nullptr); // (its index is in its parent's record already)
+	});
 	return MIRT_OK;
 }
 
 // Partition::Partition, Partition.cpp:4-14, then flatten.  Needs S.triVerts/triPrim/spheres/sphPrim/nPrims.
+// threads: 1 = everything on the calling thread; anything else = the library's thread pool.
 int build_tree(mirt_host_scene& S, uint32_t threads) {
 	const auto t0 = std::chrono::steady_clock::now();
 	Prims P;
@@ -510,15 +566,9 @@ int build_tree(mirt_host_scene& S, uint32_t threads) {
 	for (size_t i = 0; i < S.sphPrim.size(); ++i) P.slot[S.sphPrim[i]] = ~(int64_t)i;
 	P.allFinite = true;
 	for (float c : S.triVerts) if (!isfinite(c)) { P.allFinite = false; break; }
-	int nThreads = (int)threads;
-	if (nThreads <= 0) {
-		nThreads = (int)std::thread::hardware_concurrency();
-		if (nThreads > 16) nThreads = 16;
-	}
-	if (nThreads < 1) nThreads = 1;
-	if (nThreads > 64) nThreads = 64;
 	PNode* root = nullptr;
 	int rc = MIRT_OK;
+	Builder B(P, threads == 1 ? 1 : 2);
 	try {
 		// AABB box; starts as (+inf, -inf) (AABB.h:34-35), then expand over every object, AABB.cpp:157-164
 		Box box;
@@ -537,25 +587,24 @@ int build_tree(mirt_host_scene& S, uint32_t threads) {
 		}
 		root = new PNode();
 		root->box = box;
-		Builder B(P, nThreads);
 		// insert(obj, root): the root is a leaf, the object is kept iff root.box.contains(obj), Partition.cpp:55-59
 		{
-			std::vector<uint32_t> all(S.nPrims);
+			std::vector<uint32_t> all(S.nPrims), none;
 			for (uint32_t p = 0; p < S.nPrims; ++p) all[p] = p;
-			std::vector<uint8_t> side(S.nPrims);
-			B.classify(all, box, box, side.data());
-			for (uint32_t p = 0; p < S.nPrims; ++p)
-				if (side[p] & 1) root->objs.push_back(p);
+			(void)B.distribute(all, box, box, root->objs, none, !B.serial);
 		}
-		B.split(root, 0);
+		B.split(root, 0, true);
+		B.run_tasks();
 		if (B.oom.load()) rc = mirt_set_error(MIRT_E_NOMEM, "out of host memory while building the Partition tree");
-		else { S.truncatedNodes = B.truncated.load(); rc = flatten(root, S); }
+		else { S.truncatedNodes = B.truncated.load(); rc = flatten(root, S, B); }
 	} catch (const std::bad_alloc&) {
 		rc = mirt_set_error(MIRT_E_NOMEM, "out of host memory while building the Partition tree");
 	} catch (const std::exception& e) {
 		rc = mirt_set_error(MIRT_E_INVALID, "Partition build failed: %s", e.what());
 	}
-	free_tree(root);
+	// the top's nodes, then every task's subtree on the pool
+	if (root && root->task < 0) free_tree(root, true); // (a small scene's root is itself a task)
+	MirtPool::get().run((uint32_t)B.tasks.size(), [&](uint32_t t) { free_tree(B.tasks[t].node); });
 	S.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	return rc;
 }
