@@ -686,6 +686,118 @@ void set_defaults(mirt_host_scene& S) {
 	S.truncatedNodes = 0;
 }
 
+// A run of well-formed tri lines, taken in one go on all threads.  text..end starts at the beginning of a tri line.
+// First the extent of the run is found -- the first line that does not begin with "tri" and a blank, looked for in
+// rounds of 64 pieces of 64 KB (a glance per line, no parsing) -- then the run is cut into pieces at line ends and the
+// pieces are parsed side by side.  The run ends before the first line that is anything but "tri a b c" with three numbers
+// that index the vertex array (that line is left to the caller's loop, which knows what to do with it).  The triangles
+// are appended exactly as the caller's loop would append them.
+struct TriRun { uint64_t lines; size_t bytes; };
+TriRun tri_run(const char* text, const char* end, const std::vector<V3>& verts, const M4& T, mirt_host_scene& S, uint32_t curMat) {
+	const char* runEnd = text;
+	{
+		const size_t PIECE = (size_t)64 << 10;
+		const uint32_t ROUND = 64;
+		bool open = true;
+		while (open && runEnd < end && (size_t)(runEnd - text) < ((size_t)1 << 30)) {
+			// pieces of this round start at line starts: piece i begins at the first line start at or after runEnd + i * PIECE
+			const char* starts[ROUND + 1];
+			uint32_t n = 0;
+			starts[0] = runEnd;
+			while (n < ROUND && starts[n] < end) {
+				const char* c = starts[n] + PIECE;
+				const char* nl = c < end ? (const char*)memchr(c, '\n', (size_t)(end - c)) : nullptr;
+				starts[++n] = nl ? nl + 1 : end;
+			}
+			const char* stop[ROUND];
+			MirtPool::get().run(n, [&](uint32_t i) {
+				const char* p = starts[i];
+				const char* const pe = starts[i + 1];
+				while (p < pe) {
+					if (!(pe - p > 4 && p[0] == 't' && p[1] == 'r' && p[2] == 'i' && is_space(p[3]))) break;
+					const char* eol = (const char*)memchr(p, '\n', (size_t)(pe - p));
+					p = eol ? eol + 1 : pe;
+				}
+				stop[i] = p;
+			});
+			for (uint32_t i = 0; i < n; ++i) {
+				runEnd = stop[i];
+				if (stop[i] < starts[i + 1]) { open = false; break; }
+			}
+		}
+	}
+	if (runEnd == text) return TriRun{0, 0};
+	const size_t want = (size_t)(runEnd - text) / (4 * (size_t)MirtPool::get().threads()) + 1;
+	const size_t PIECE = want < ((size_t)64 << 10) ? ((size_t)64 << 10) : want;
+	std::vector<const char*> cut; // piece i = [cut[i], cut[i+1])
+	cut.push_back(text);
+	while (cut.back() < runEnd) {
+		const char* c = cut.back() + PIECE;
+		if (c >= runEnd) { cut.push_back(runEnd); break; }
+		const char* nl = (const char*)memchr(c, '\n', (size_t)(runEnd - c));
+		cut.push_back(nl ? nl + 1 : runEnd);
+	}
+	const uint32_t pieces = (uint32_t)cut.size() - 1;
+	struct Piece { std::vector<int> idx; size_t goodBytes; bool whole; };
+	std::vector<Piece> pc(pieces);
+	MirtPool::get().run(pieces, [&](uint32_t i) {
+		Piece& k = pc[i];
+		k.idx.reserve(3 * (size_t)(cut[i + 1] - cut[i]) / 12);
+		const char* p = cut[i];
+		const char* const pe = cut[i + 1];
+		k.whole = true;
+		while (p < pe) {
+			const char* eol = (const char*)memchr(p, '\n', (size_t)(pe - p));
+			const char* le = eol ? eol : pe;
+			const char* q = p;
+			float v[3];
+			// exactly the plain case: "tri" in column 0, three values, indices inside the array
+			bool good = le - p > 4 && p[0] == 't' && p[1] == 'r' && p[2] == 'i' && is_space(p[3]);
+			if (good) { q = p + 3; good = read_vals(q, le, 3, v); }
+			if (good) {
+				const int i0 = (int)v[0], i1 = (int)v[1], i2 = (int)v[2];
+				good = i0 >= 0 && i1 >= 0 && i2 >= 0 && (size_t)i0 < verts.size() && (size_t)i1 < verts.size() && (size_t)i2 < verts.size();
+				if (good) { k.idx.push_back(i0); k.idx.push_back(i1); k.idx.push_back(i2); }
+			}
+			if (!good) { k.whole = false; break; }
+			p = eol ? eol + 1 : pe;
+		}
+		k.goodBytes = (size_t)(p - cut[i]);
+	});
+	// the run: whole pieces, then the good start of the first piece that is not whole
+	uint32_t used = 0;
+	uint64_t lines = 0;
+	size_t bytes = 0;
+	std::vector<uint64_t> first(pieces + 1, 0);
+	for (uint32_t i = 0; i < pieces; ++i) {
+		first[i] = lines;
+		lines += pc[i].idx.size() / 3;
+		bytes += pc[i].goodBytes;
+		++used;
+		if (!pc[i].whole) break;
+	}
+	if (lines == 0) return TriRun{0, 0};
+	const size_t tri0 = S.triPrim.size();
+	const uint32_t prim0 = S.nPrims;
+	S.triVerts.resize((tri0 + lines) * 9);
+	S.triPrim.resize(tri0 + lines);
+	S.primMaterial.resize(S.primMaterial.size() + lines, curMat);
+	S.nPrims += (uint32_t)lines;
+	MirtPool::get().run(used, [&](uint32_t i) {
+		const Piece& k = pc[i];
+		float* out = S.triVerts.data() + (tri0 + first[i]) * 9;
+		for (size_t t = 0; t < k.idx.size() / 3; ++t) {
+			for (int c = 0; c < 3; ++c) { // Triangle.cpp:23-25
+				const V3 in = verts[(size_t)k.idx[3 * t + c]];
+				const V4 w = mul(T, v4(in.x, in.y, in.z, 1.0f));
+				*out++ = w.x; *out++ = w.y; *out++ = w.z;
+			}
+			S.triPrim[tri0 + first[i] + t] = prim0 + (uint32_t)(first[i] + t);
+		}
+	});
+	return TriRun{lines, bytes};
+}
+
 int parse_text(const char* text, size_t len, mirt_host_scene& S) {
 	const auto t0 = std::chrono::steady_clock::now();
 	float diffuse[3] = { 0, 0, 0 }, specular[3] = { 0, 0, 0 }, emission[3] = { 0, 0, 0 }, ambient[3] = { 0.2f, 0.2f, 0.2f }; // Scene.cpp:16
@@ -700,6 +812,7 @@ int parse_text(const char* text, size_t len, mirt_host_scene& S) {
 	const char* p = text;
 	const char* const end = text + len;
 	uint64_t lineNo = 0;
+	uint32_t triStreak = 0; // tri lines in a row so far
 	while (p < end) {
 		const char* eol = (const char*)memchr(p, '\n', (size_t)(end - p));
 		const char* le = eol ? eol : end;
@@ -715,6 +828,18 @@ int parse_text(const char* text, size_t len, mirt_host_scene& S) {
 		auto is = [&](const char* name) { return strlen(name) == cl && memcmp(cb, name, cl) == 0; };
 		float v[10];
 		if (is("tri")) { // :158-165
+			// A long run of tri lines (a mesh) is taken by all threads: see tri_run.  Only after 64 of them in a row, and with
+			// the material of the run interned, so that the loop below is what handles everything unusual.
+			if (triStreak >= 64 && !matDirty && haveVerts && (size_t)(end - ls) > (1u << 20)) {
+				const TriRun run = tri_run(ls, end, verts, stack.back(), S, curMat);
+				if (run.lines) {
+					p = ls + run.bytes;
+					lineNo += run.lines - 1;
+					continue;
+				}
+				triStreak = 0; // the next line is not a plain tri line: back to one line at a time
+			}
+			++triStreak;
 			if (!read_vals(q, le, 3, v)) continue;
 			if (!haveVerts) return mirt_set_error(MIRT_E_INVALID, "line %llu: tri before maxverts", (unsigned long long)lineNo);
 			const int i0 = (int)v[0], i1 = (int)v[1], i2 = (int)v[2];
@@ -736,7 +861,7 @@ int parse_text(const char* text, size_t len, mirt_host_scene& S) {
 			S.triPrim.push_back(S.nPrims++);
 			S.primMaterial.push_back(curMat);
 		}
-		else if (is("vertex")) { // :75-81
+		else if ((triStreak = 0, is("vertex"))) { // :75-81
 			if (!read_vals(q, le, 3, v)) continue;
 			if (!haveVerts || vertIndex >= verts.size()) return mirt_set_error(MIRT_E_INVALID, "line %llu: more vertices than maxverts", (unsigned long long)lineNo);
 			verts[vertIndex++] = v3(v[0], v[1], v[2]);

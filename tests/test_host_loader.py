@@ -116,3 +116,53 @@ def test_png_errors():
         write_png("/nonexistent_dir/x.png", np.zeros((2, 2, 3), np.uint8))
     with pytest.raises(ValueError):
         write_png("/tmp/x.png", np.zeros((2, 2), np.uint8))
+
+
+def _mesh_text(n_verts, tris, extra_head=""):
+    rng = np.random.default_rng(5)
+    v = rng.uniform(-1, 1, size=(n_verts, 3)).astype(np.float32)
+    v = np.array([[np.float32("%.6f" % c) for c in x] for x in v], np.float32)  # the values as the text below spells them
+    head = "size 8 8\ncamera 0 0 5 0 0 0 0 1 0 45\n" + extra_head + "maxverts %d\n" % n_verts
+    head += "".join("vertex %.6f %.6f %.6f\n" % tuple(x) for x in v)
+    return head, v, tris
+
+
+def test_long_runs_of_tri_lines_parse_like_single_lines():
+    """Meshes -- tens of thousands of tri lines in a row -- are parsed by all threads at once; everything the one-line-at-a-time
+    loop does with unusual lines inside such a run must come out the same: a tri line with too few numbers is skipped
+    (Scene.cpp:235-244 readvals fails), indented lines and comments are fine, transforms change between runs."""
+    n_verts, n = 500, 150000
+    rng = np.random.default_rng(6)
+    idx = rng.integers(0, n_verts, size=(n, 3))
+    head, v, _ = _mesh_text(n_verts, idx)
+    lines = ["tri %d %d %d" % tuple(t) for t in idx]
+    expect = list(range(n))
+    lines[70000] = "tri 1 2"                      # skipped
+    expect.remove(70000)
+    lines[90000] = "  tri %d %d %d" % tuple(idx[90000])  # indented: still a tri line
+    lines[100000] = "# comment\n" + lines[100000]
+    lines[120000] = "translate 1 2 3\n" + lines[120000]   # from here on the vertices are moved
+    text = head + "\n".join(lines) + "\n"
+    flat = FlatScene.from_text(text)
+    assert flat.n_prims == n - 1
+    got = flat.tri_verts.reshape(-1, 3, 3)
+    want = v[idx[expect]]
+    moved = np.array(expect) >= 120000
+    want = want.copy()
+    want[moved] = (want[moved] + np.float32([1, 2, 3])).astype(np.float32)
+    assert np.array_equal(got, want)
+    assert np.array_equal(flat.tri_prim, np.arange(n - 1, dtype=np.uint32))
+    assert len(set(flat.prim_material.tolist())) == 1
+
+
+def test_error_inside_a_long_run_names_its_line():
+    n_verts, n = 100, 100000
+    rng = np.random.default_rng(7)
+    idx = rng.integers(0, n_verts, size=(n, 3))
+    head, _, _ = _mesh_text(n_verts, idx)
+    lines = ["tri %d %d %d" % tuple(t) for t in idx]
+    lines[81234] = "tri 1 2 %d" % n_verts  # one past the end of the vertex array
+    text = head + "\n".join(lines) + "\n"
+    line_no = head.count("\n") + 81234 + 1
+    with pytest.raises(ValueError, match="line %d: vertex index outside maxverts" % line_no):
+        FlatScene.from_text(text)
