@@ -17,10 +17,12 @@ def q(s, k):
     return v.value
 with DeviceScene(flat, 0, lib=lib) as s:
     s.render(w, h)
-    for k in range(140, 149): q(s, k)
+    for k in range(140, 156): q(s, k)
     _, st = s.render(w, h)
     t0 = (~q(s, 140)) & (2**64 - 1); tend = q(s, 141); ex0 = (~q(s, 142)) & (2**64 - 1); ex1 = q(s, 143)
     life, tail, waves, rounds, lanes = (q(s, k) for k in range(144, 149))
     us = lambda t: t / 100.0
     print("device_ms %.3f; slots exhausted at %.0f .. %.0f us, last wave ended at %.0f us" % (st["device_ms"], us(ex0 - t0), us(ex1 - t0), us(tend - t0)))
     print("waves %d, mean lifetime %.0f us, mean time after exhaustion %.0f us, rounds per wave %.1f, lanes per round %.1f" % (waves, us(life / waves), us(tail / waves), rounds / waves, lanes / max(1, rounds)))
+    mx = [q(s, k) for k in range(149, 152)]; sm = [q(s, k) for k in range(152, 155)]
+    print("longest round (camera, light, reflection) %s us; share of the summed round time %s" % ([round(us(x)) for x in mx], [round(x / max(1, sum(sm)), 3) for x in sm]))
