@@ -410,6 +410,8 @@ __device__ __forceinline__ uint32_t membership(const DScene& S, const RayCtx& r,
 #ifndef FRAME_BLOCK
 #define FRAME_BLOCK 64
 #endif
+// (k_trace keeps four waves to a block: with one, the 10-million-triangle scene and the Stanford dragon on the per-depth
+// path both came out 2-2.5 % slower)
 
 // Traversal stack: STACK_LDS entries per lane in LDS ([entry][lane]: conflict-free, no address arithmetic beyond a
 // shift).  Hierarchies deeper than that (OVF = true, chosen by the host from the built depth) keep the deeper entries in
