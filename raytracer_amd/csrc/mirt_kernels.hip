@@ -531,6 +531,8 @@ struct Walker {
 		}
 #define MIRT_CSWAP(i, j) { const bool sw = key[j] < key[i]; const uint32_t ki = key[i], ri = ref[i]; \
 		key[i] = sw ? key[j] : ki; ref[i] = sw ? ref[j] : ri; key[j] = sw ? ki : key[j]; ref[j] = sw ? ri : ref[j]; }
+		// (all five comparators: with four -- middle pair left as it falls -- or three -- only the nearest child in its place --
+		// the step is 6 and 12 instructions shorter and the Stanford dragon 2 % slower: the order of the pushes matters more)
 		MIRT_CSWAP(0, 1) MIRT_CSWAP(2, 3) MIRT_CSWAP(0, 2) MIRT_CSWAP(1, 3) MIRT_CSWAP(1, 2)
 #undef MIRT_CSWAP
 		if (key[0] == 0xffffffffu) {
