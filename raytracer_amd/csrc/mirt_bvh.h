@@ -43,7 +43,8 @@ struct BvhNode {
 };
 
 struct BvhBuilder {
-	static const int BINS = 16;
+	static const int BINS = 32; // (Stanford dragon: 1.3 % fewer wave steps per frame than with 16; 64 bins, or trying every split position in
+	                            // ranges of up to 256 primitives, take off another 0.1 %)
 #ifndef MIRT_LEAF_MIN
 #define MIRT_LEAF_MIN 1
 #endif
