@@ -292,6 +292,14 @@ def main():
         raise SystemExit("bench self-check FAILED: frames of streams %s differ from the frame rendered alone" % bad)
     if not bool(check.any()):
         raise SystemExit("bench self-check FAILED: the frame is all black")
+    if world > 1 and rank == 0:
+        # several GPUs: the image assembled from every rank's tiles must equal the whole image rendered by one GPU
+        whole = torch.empty(width * height * 3, dtype=torch.uint8, device="cuda")
+        with torch.cuda.stream(check_stream):
+            scene.render_device(multigpu.rank_params(width, height, 0, 1, trace_mode=trace_mode), whole.data_ptr(), whole.numel(), check_stream.cuda_stream)
+        torch.cuda.synchronize()
+        if not torch.equal(images[(frame_no[0] - 1) % depth], whole):
+            raise SystemExit("bench self-check FAILED: the image assembled from %d ranks differs from the image rendered by one GPU" % world)
     scene.release_stream(check_stream.cuda_stream)
     # counted as the reference spawns them; the last two entries: shadow and reflection rays the device really walked
     # (a shadow query whose light term is multiplied by an exact zero is answered without a walk)
@@ -359,7 +367,7 @@ def main():
             },
             "rays_per_frame": {"primary": int(rays[0]), "shadow": int(rays[1]), "reflection": int(rays[2])},
             "rays_walked_per_frame": {"primary": int(rays[0]), "shadow": int(rays[3]), "reflection": int(rays[4])},
-            "self_check": "last frame of each of the %d streams byte-equal to a frame rendered alone" % depth,
+            "self_check": "last frame of each of the %d streams byte-equal to a frame rendered alone" % depth + ("; image assembled from %d ranks byte-equal to the whole image rendered by one GPU" % world if world > 1 else ""),
             "frame_alone_ms": frame_alone_ms,   # one frame with nothing else on the GPU: clears + every launch
             "sync_host_ms": sync_host_ms,       # mirt_render: the same plus the copy into the caller's host buffer, host clock
             "kernels": kern,                    # launch durations inside the timed region (launches of frames in flight share the GPU)
