@@ -494,6 +494,9 @@ struct Walker {
 		STAT_WAVE(S, 0); // node steps (wave iterations)
 		STAT_LANE(S, 1); // node steps (lanes)
 		const uint4* nd = (const uint4*)S.bvh + (size_t)cur * 4;
+		// (The vector memory path takes about one cycle per lane and 16-byte request -- exp/ta/ta_bench.hip: 258 cycles for a
+		// wave's four requests per lane -- yet it is not what holds the walk up: a FIFTH request per node step, waited for,
+		// left the Stanford dragon's frame rate where it was.  A 48-byte node would buy nothing.)
 		const uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
 		// scale/d per axis: the node stores signed power-of-two exponents
 		const float ax = __builtin_ldexpf(r.ie.x, (int)(q0.w << 24) >> 24);
