@@ -68,3 +68,37 @@ def test_command_line_starts_from_the_cache_the_second_time(tmp_path, goldens, m
     b, _, lines = render_file("/nonexistent/scene6.test", out_path=str(tmp_path / "b.png"), cache=cache)  # the text is not read again
     assert np.array_equal(a, b) and np.array_equal(a, goldens("c1_cornell")["bgr"])
     assert any("Scene cache" in l for l in lines)
+
+
+_WRITE_CACHE = r'''
+import sys
+sys.path.insert(0, %r)
+from raytracer_amd import workloads
+from raytracer_amd.device import DeviceScene
+from raytracer_amd.scene import FlatScene
+flat = FlatScene.from_text(workloads.dragon_grid(640, 360, nx=2, nz=2))   # 400 000 triangles: large ranges, subtree tasks
+with DeviceScene(flat, 0) as s:
+    s.save(sys.argv[1])
+'''
+
+
+def test_scene_preparation_does_not_depend_on_the_thread_count(tmp_path):
+    """The whole hand-over -- text parsed in pieces, Partition tree from tasks, membership lists, hierarchy build, collapse and
+    packing on the worker pool -- gives the same device arrays on one thread as on five: the cache files of two processes are
+    equal byte for byte behind the record that holds device addresses."""
+    import os
+    import struct
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    blobs = []
+    for threads in (1, 5):
+        path = str(tmp_path / ("t%d.mirt" % threads))
+        env = dict(os.environ, MIRT_THREADS=str(threads))
+        subprocess.run([sys.executable, "-c", _WRITE_CACHE % root, path], env=env, check=True, timeout=600)
+        raw = open(path, "rb").read()
+        magic, version, dscene_bytes, meta_bytes = struct.unpack_from("<8sIII", raw, 0)
+        assert magic == b"MIRTSCN1"
+        header = 8 + 4 * 4 + 4 * 4 + 8
+        blobs.append(raw[header + dscene_bytes:])   # SceneMeta and the eleven arrays
+    assert len(blobs[0]) == len(blobs[1]) and blobs[0] == blobs[1]
