@@ -402,6 +402,9 @@ struct Packer {
 
 // Collapses the binary primitive hierarchy into 4-wide nodes with quantised child boxes (layout in mirt_device.h).
 // Parallel in the same way as Packer: one thread near the root, subtrees over at most TASK_PRIMS primitives on the pool.
+#ifndef MIRT_BVH_FAMILY_ORDER
+#define MIRT_BVH_FAMILY_ORDER 1
+#endif
 struct Collapser {
 	const BvhBuilder& bb;
 	const std::vector<uint32_t>& kindIndex;
@@ -417,10 +420,17 @@ struct Collapser {
 		return BVH_LEAF | (n.kind ? BVH_SPHERES : 0u) | ((n.count - 1) << BVH_COUNT_SHIFT) | kindIndex[n.first];
 	}
 	// acc: entries the walk can hold on its stack when it arrives at this node (siblings left behind by the ancestors)
-	uint32_t emit(Out& o, int32_t i, uint32_t depth, uint32_t acc, std::vector<Task>* tasks) const {
+	// slot: the place kept for this node by its parent (NO_SLOT: the next free one).  The interior children of a node get
+	// places next to each other before any of them is filled in: a walk that goes from a node to one child and later to
+	// its siblings finds them in the same or the neighbouring cache line (depth-first order puts only the first child near).
+	static const uint32_t NO_SLOT = 0xffffffffu;
+	uint32_t emit(Out& o, int32_t i, uint32_t depth, uint32_t acc, std::vector<Task>* tasks, uint32_t slot = NO_SLOT) const {
 		if (depth > o.maxDepth) o.maxDepth = depth;
-		const uint32_t me = (uint32_t)(o.w.size() / 16);
-		o.w.resize(o.w.size() + 16, 0u);
+		uint32_t me = slot;
+		if (me == NO_SLOT) {
+			me = (uint32_t)(o.w.size() / 16);
+			o.w.resize(o.w.size() + 16, 0u);
+		}
 		// up to four children: open the interior child with the largest surface area until none is left or there are four
 		int32_t ch[4] = { bb.nodes[i].left, bb.nodes[i].right, -1, -1 };
 		int n = 2;
@@ -477,11 +487,22 @@ struct Collapser {
 		const uint32_t below = acc + (uint32_t)n - 1u; // a step pushes every hit child but the one it goes to
 		if (below > o.maxStack) o.maxStack = below;
 		memcpy(o.w.data() + (size_t)me * 16, w, sizeof w);
+#if MIRT_BVH_FAMILY_ORDER
+		uint32_t place[4] = {NO_SLOT, NO_SLOT, NO_SLOT, NO_SLOT};
+		for (int c = 0; c < n; ++c) {
+			const BvhNode& cn = bb.nodes[ch[c]];
+			if (cn.left < 0 || (tasks && cn.count <= TASK_PRIMS)) continue;
+			place[c] = (uint32_t)(o.w.size() / 16);
+			o.w.resize(o.w.size() + 16, 0u);
+		}
+#else
+		const uint32_t place[4] = {NO_SLOT, NO_SLOT, NO_SLOT, NO_SLOT};
+#endif
 		for (int c = 0; c < n; ++c) {
 			const BvhNode& cn = bb.nodes[ch[c]];
 			if (cn.left < 0) refs[c] = leafRef(cn);
 			else if (tasks && cn.count <= TASK_PRIMS) tasks->push_back(Task{ch[c], depth + 1, below, me, c}); // patched in later
-			else refs[c] = emit(o, ch[c], depth + 1, below, tasks);
+			else refs[c] = emit(o, ch[c], depth + 1, below, tasks, place[c]);
 		}
 		memcpy(o.w.data() + (size_t)me * 16 + 10, refs, sizeof refs);
 		return me;
