@@ -236,7 +236,9 @@ def main():
     nbytes = multigpu.per_rank_bytes(width, height, world) if world > 1 else width * height * 3
     # frames are issued round-robin on `pipeline` streams; the library keeps one workspace per stream, so the short
     # latency-bound deep-bounce launches of one frame overlap the bulk of the next
-    depth = args.pipeline if args.pipeline > 0 else FRAMES_IN_FLIGHT
+    # (several GPUs: a rank's share of the frame is small and its launches are short; 16 in flight -- one per hardware queue --
+    # keep a GPU busy where 8 leave a quarter of it idle: a rank of eight 0.139 against 0.165 ms per frame)
+    depth = args.pipeline if args.pipeline > 0 else (FRAMES_IN_FLIGHT if world == 1 else 16)
     streams = [torch.cuda.Stream() for _ in range(depth)]
     locals_ = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(depth)]
     images = [torch.empty(width * height * 3, dtype=torch.uint8, device="cuda") for _ in range(depth)] if (world > 1 and rank == 0) else None

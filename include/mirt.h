@@ -191,7 +191,7 @@ int mirt_render(mirt_scene* scene, const mirt_render_params* params, uint8_t* bg
  * B,G,R per pixel, edge tiles padded to full size (mirt_tile_buffer_bytes gives the size).  With
  * tile_stride == 1 and tile_w == 0 the layout is the plain width*height*3 image instead.  hip_stream is a
  * hipStream_t (NULL = default stream).  No host synchronisation happens inside the call.
- * The library keeps one workspace per stream (allocated at the stream's first frame, at most 16 streams per scene), so
+ * The library keeps one workspace per stream (allocated at the stream's first frame, at most 64 streams per scene), so
  * frames issued on different streams overlap on the GPU; that is how many frames are rendered fastest, because the
  * short launches of a frame's deep bounces leave most of the GPU idle.  HIP maps a process's streams onto
  * GPU_MAX_HW_QUEUES hardware queues (environment variable, read when HIP initialises; default 4) and streams that share
