@@ -929,15 +929,15 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 	if (single) {
 		// Waves of the launch per SIMD.  A frame alone wants every place on the GPU (7): its time is the chain of rounds
 		// behind its last batches, and more waves make every chain shorter.  A frame that shares the GPU with frames on
-		// other streams wants waves with enough batches each to gather their hits into full rounds -- about 22 batches of
-		// 64 pixel slots per wave: an eighth of a 4K frame (one rank of eight) then runs on 1 wave per SIMD and takes
-		// 0.138 ms per frame instead of 0.165, a 1080p frame 0.30 instead of 0.35; a whole 4K frame stays at 6-7 either way.
-		// MIRT_FRAME_GRID=n fixes the number.
+		// other streams wants waves with enough batches each to gather their hits into full rounds -- about 64 batches of
+		// 64 pixel slots per wave.  Measured, 16 hardware queues: a whole 4K frame 0.894 ms per frame on 2 waves per SIMD
+		// against 0.933 on 7 (and 0.953 on 1); half of it (one rank of two) 0.452 on 1 against 0.477 on 3; an eighth 0.138
+		// on 1 against 0.165 on 7; a 1080p frame 0.303 against 0.346.  MIRT_FRAME_GRID=n fixes the number.
 		static const int gwEnv = []() { const char* e = getenv("MIRT_FRAME_GRID"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= MIRT_FRAME_WAVES ? v : 0; }();
 		int gw = MIRT_FRAME_WAVES;
 		if (gwEnv) gw = gwEnv;
 		else if (othersInFlight >= 3) {
-			const uint64_t nBatches = ((uint64_t)g.nSlots + 63u) / 64u, perWave = (uint64_t)s->numCUs * 4u * 22u;
+			const uint64_t nBatches = ((uint64_t)g.nSlots + 63u) / 64u, perWave = (uint64_t)s->numCUs * 4u * 64u;
 			const uint64_t want = (nBatches + perWave / 2) / perWave;
 			gw = want < 1 ? 1 : (want > (uint64_t)MIRT_FRAME_WAVES ? MIRT_FRAME_WAVES : (int)want);
 			if (nBatches < 8192u) gw = 2; // (a 640x480 frame: 2 beats 1 and 7 by 3 %)
