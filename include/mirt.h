@@ -193,7 +193,9 @@ int mirt_render(mirt_scene* scene, const mirt_render_params* params, uint8_t* bg
  * hipStream_t (NULL = default stream).  No host synchronisation happens inside the call.
  * The library keeps one workspace per stream (allocated at the stream's first frame, at most 64 streams per scene), so
  * frames issued on different streams overlap on the GPU; that is how many frames are rendered fastest, because the
- * short launches of a frame's deep bounces leave most of the GPU idle.  HIP maps a process's streams onto
+ * end of a frame -- the chain of bounces behind its last pixels -- leaves most of the GPU idle.  A frame that finds three
+ * or more frames of the scene still in flight on other streams is launched with fewer, longer-lived waves (best
+ * throughput); a frame that finds the GPU to itself with as many as fit (shortest time).  HIP maps a process's streams onto
  * GPU_MAX_HW_QUEUES hardware queues (environment variable, read when HIP initialises; default 4) and streams that share
  * a queue do not overlap: give the process at least as many queues as frames in flight. */
 int mirt_render_device(mirt_scene* scene, const mirt_render_params* params, void* d_out, size_t d_out_bytes, void* hip_stream);
