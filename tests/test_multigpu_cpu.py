@@ -36,6 +36,13 @@ def _worker(rank, world, port, w, h, q):
     packed = torch.from_numpy(multigpu.pack_tiles_host(img, rank, world))
     assert packed.numel() == multigpu.per_rank_bytes(w, h, world)
     got = multigpu.gather_to_root(packed, world, rank, dist)
+    # the same into a landing area allocated once (what bench.py does per stream): same bytes, the same tensor comes back
+    landing = torch.full((world, packed.numel()), 0x5a, dtype=torch.uint8) if rank == 0 else None
+    again = multigpu.gather_to_root(packed, world, rank, dist, out=landing)
+    if rank == 0:
+        assert again is landing and torch.equal(again, got)
+    else:
+        assert again is None and got is None
     rays = torch.tensor([st["primary_rays"], st["shadow_rays"], st["reflection_rays"]], dtype=torch.int64)
     dist.all_reduce(rays)
     if rank == 0:
