@@ -921,6 +921,23 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 	F.divTilesX = make_div(g.tilesX);
 	// bytes of tiles that are not rendered must stay untouched in the full-image layout, so only clear when all are
 	F.preCleared = (packed || p->tile_stride == 1) ? 1u : 0u;
+	// The order of k_frame's batches.  In image order the blocks that see the scene come in long runs (the rows the object
+	// covers) between runs that see nothing, and all waves are in the same kind of run at the same time.  Stepping through
+	// the blocks with a stride of about 1/128 of the frame (made coprime to the number of blocks, so every block comes
+	// exactly once) mixes the two at every moment: Stanford dragon 4K +2.5 % with frames in flight, 8K +8 % and 7 % less for a
+	// frame alone; frames below 1080p do not care.  (Handing out the blocks that see the scene FIRST does the opposite.)
+	// MIRT_BATCH_STRIDE=0: image order.
+	F.batchMul = 0;
+	if (single) {
+		static const bool strided = []() { const char* e = getenv("MIRT_BATCH_STRIDE"); return !e || atoi(e) != 0; }();
+		const uint64_t nb = (g.nSlots + 63) / 64;
+		if (strided && nb >= 16384) {
+			uint64_t m = (nb / 128) | 1u;
+			auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
+			while (gcd(m, nb) != 1) m += 2;
+			F.batchMul = (uint32_t)m;
+		}
+	}
 	HIPCHK(hipMemsetAsync(F.counters, 0, CTR_COUNT * 4, st));
 	if (F.preCleared) {
 		HIPCHK(hipMemsetAsync(d_out, 0, need, st));

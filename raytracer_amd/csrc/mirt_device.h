@@ -115,6 +115,7 @@ struct DFrame {
 	uint32_t packedTiles; // output layout: 0 = full image, 1 = packed tile buffer
 	uint32_t refillMin;   // k_trace<REFILL>: parked lanes that trigger a refill
 	uint32_t preCleared;  // the output buffer and pathDepth were zeroed before the frame: missed primary rays store nothing
+	uint32_t batchMul;    // k_frame hands out 8x8 pixel block (b * batchMul) mod nBatches as its b-th batch (0: block b)
 	FastDiv divArea, divSbx, divTilesX; // tile area, 8x8 blocks per tile row, tiles per image row
 };
 

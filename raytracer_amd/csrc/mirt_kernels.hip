@@ -1244,8 +1244,10 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 				// up to 64 camera rays (main.cpp:152-153, depth 0)
 				round = ROUND_PRIMARY;
 				pfirst = false;
-				tag = pbatch * 64u + (uint32_t)lane;
-				const uint32_t got = F.nSlots - pbatch * 64u < 64u ? F.nSlots - pbatch * 64u : 64u;
+				// (batches are not handed out in image order: see where the host sets batchMul)
+				const uint32_t batch = F.batchMul ? (uint32_t)(((unsigned long long)pbatch * F.batchMul) % nBatches) : pbatch;
+				tag = batch * 64u + (uint32_t)lane;
+				const uint32_t got = F.nSlots - batch * 64u < 64u ? F.nSlots - batch * 64u : 64u;
 				if ((uint32_t)lane < got) {
 					uint32_t px, py, inTile;
 					if (slot_to_pixel(F, tag, px, py, inTile)) { // false: padding pixel of an edge tile
