@@ -929,10 +929,10 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 	// MIRT_BATCH_STRIDE=0: image order.
 	F.batchMul = 0;
 	if (single) {
-		static const bool strided = []() { const char* e = getenv("MIRT_BATCH_STRIDE"); return !e || atoi(e) != 0; }();
+		static const int parts = []() { const char* e = getenv("MIRT_BATCH_STRIDE"); const int v = e ? atoi(e) : 128; return v < 0 ? 0 : v; }(); // (a number: that fraction of the frame)
 		const uint64_t nb = (g.nSlots + 63) / 64;
-		if (strided && nb >= 16384) {
-			uint64_t m = (nb / 128) | 1u;
+		if (parts && nb >= 16384) {
+			uint64_t m = (nb / (uint64_t)parts) | 1u;
 			auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
 			while (gcd(m, nb) != 1) m += 2;
 			F.batchMul = (uint32_t)m;
