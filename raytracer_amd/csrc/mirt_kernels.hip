@@ -419,6 +419,7 @@ __device__ __forceinline__ uint32_t membership(const DScene& S, const RayCtx& r,
 // (a merged pointer would turn every pop into a flat_load).
 template <bool OVF, int NLDS = STACK_LDS, int STRIDE = BLOCK>
 struct LdsStack {
+	static constexpr int stride = STRIDE, nlds = NLDS;
 	uint32_t* lds;   // this thread's column
 	uint32_t* ovf;   // [level][global thread], this thread's column
 	uint32_t ovfStride;
@@ -795,6 +796,135 @@ __device__ __forceinline__ void walk_wave(const DScene& S, Walker<MODE, OVF>& w,
 	}
 }
 
+// walk_wave for a wave whose lanes need not keep to their own rays (k_frame, MODE_EXACT, the deferred walk only).
+// A round lasts as long as its longest ray: 64 secondary rays of the Stanford dragon take 55 wave iterations, their mean
+// ray 16.  Here a lane that has nothing of its own left -- no ray in this round, or a ray that ended without a hit, so that
+// no result waits in its registers -- takes the BOTTOM entry of a walking lane's traversal stack (the farthest and largest
+// subtree still to be visited) together with a copy of that lane's ray, and walks it.  The lanes of one ray form a group
+// named after the ray's own lane ("owner"):
+//   * the group's culling bound lives in s_cull[owner] (bit pattern of a non-negative float, lowered with an atomic min by
+//     whoever finds a nearer candidate, read by all before every step); 0 = a shadow query has its answer, everybody stops;
+//   * a stolen entry is overwritten with BVH_DONE: stolen entries are always the lowest ones of a stack, so a lane that
+//     pops one has nothing left below it and ends as if its stack were empty;
+//   * when all lanes are done, the helpers' candidates are folded into the owner's with an atomic min over
+//     (distance bits, primitive) in LDS; two different primitives at the winning distance, or a tie seen by any lane of the
+//     group, send the ray to the strict walk exactly as a tie inside one lane does.  The answer is the one the lane would
+//     have found alone: the subtrees are disjoint, every candidate no farther than the best is still visited (the shared
+//     bound is never below the bound of a lane walking alone at the same point), and the rule for ties is the same.
+// An owner that has given work away keeps its ray (verify() and the hit record need it) and does not help others.
+// grp: bits 0-5 owner, bit 6 "owner that gave work away", bits 8+ number of stolen entries at the bottom of the own stack.
+// s_cull: 64 words of LDS of this wave; s_key: 64 x 8 bytes of LDS of this wave that nothing else uses once every walk
+// of the wave has ended (the traversal stacks' own space).  `base`: the wave's lane-0 column of the traversal stack.
+#ifndef MIRT_SHARE_MIN_FREE
+#define MIRT_SHARE_MIN_FREE 16 // lanes without a walk before work is handed over
+#define MIRT_SHARE_GAP 4       // wave iterations between two hand-overs at least
+#endif
+#ifndef MIRT_SHARE_FIRST
+#define MIRT_SHARE_FIRST 4     // wave iterations before the first hand-over of a round
+#endif
+template <int MODE, bool OVF, class STK>
+__device__ __forceinline__ void walk_wave_share(const DScene& S, Walker<MODE, OVF>& w, STK& stk, uint32_t* base, uint32_t* s_cull, unsigned long long* s_key) {
+	const uint32_t lane = threadIdx.x & 63u;
+	const unsigned long long ltMask = (1ull << lane) - 1ull;
+	uint32_t grp = lane;
+	bool shared = false; // (uniform) some ray of the wave is walked by more than one lane
+	int gap = MIRT_SHARE_GAP - MIRT_SHARE_FIRST; // (uniform)
+	s_cull[lane] = __float_as_uint(w.tcull);
+	for (;;) {
+		// (asking for the group's bound here and using it after the step, so that the step's loads hide the LDS latency, was
+		// slower: 13.9 against 14.25 Grays/s on the Stanford dragon)
+		if (shared) {
+			const uint32_t sc = s_cull[grp & 63u];
+			if (sc == 0u) w.cur = BVH_DONE;
+			else w.tcull = fminf(w.tcull, __uint_as_float(sc));
+		}
+		const int c = (int)w.cur;
+		const bool wantNode = c >= 0, wantLeaf = c < -1;
+		const uint32_t nNode = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(wantNode)), nLeaf = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(wantLeaf));
+		if (nNode + nLeaf == 0u) break;
+		++gap;
+		if (64u - (nNode + nLeaf) >= MIRT_SHARE_MIN_FREE && gap >= MIRT_SHARE_GAP) {
+			const bool free = c == -1 && w.best.ref == REF_NONE && !w.needStrict && !(grp & 64u);
+			const bool gives = c != -1 && w.sp > (int)(grp >> 8) && (grp >> 8) < (uint32_t)STK::nlds;
+			const unsigned long long freeM = __builtin_amdgcn_ballot_w64(free), giveM = __builtin_amdgcn_ballot_w64(gives);
+			const uint32_t nF = (uint32_t)__popcll(freeM), nG = (uint32_t)__popcll(giveM);
+			if (nF >= MIRT_SHARE_MIN_FREE / 2 && nG) {
+#if MIRT_TIMELINE
+				if (lane == 0) { atomicAdd(S.dbg + 12, 1ull); atomicAdd(S.dbg + 13, (unsigned long long)(nF < nG ? nF : nG)); }
+#endif
+				gap = 0;
+				shared = true;
+				const uint32_t rankF = (uint32_t)__popcll(freeM & ltMask), rankG = (uint32_t)__popcll(giveM & ltMask);
+				// the k-th giving lane's number goes to lane k (every lane sends to a lane of its own), the k-th free lane picks it up there
+				const uint32_t dest = gives ? rankG : nG + (uint32_t)__popcll(~giveM & ltMask);
+				const uint32_t packed = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)lane);
+				const uint32_t from = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rankF << 2), (int)packed);
+				const bool takes = free && rankF < nG;
+				const bool robbed = gives && rankG < nF;
+				// the giving lanes bring the group's bound up to date first
+				if (robbed) atomicMin(s_cull + (grp & 63u), __float_as_uint(w.tcull));
+				const int src = (int)((takes ? from : lane) << 2);
+#define MIRT_PULL(x) __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(x)))
+				const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)grp);
+				const float ox = MIRT_PULL(w.r.o.x), oy = MIRT_PULL(w.r.o.y), oz = MIRT_PULL(w.r.o.z);
+				const float dx = MIRT_PULL(w.r.d.x), dy = MIRT_PULL(w.r.d.y), dz = MIRT_PULL(w.r.d.z);
+				const float ix = MIRT_PULL(w.r.ie.x), iy = MIRT_PULL(w.r.ie.y), iz = MIRT_PULL(w.r.ie.z);
+				const float px = MIRT_PULL(w.r.oie.x), py = MIRT_PULL(w.r.oie.y), pz = MIRT_PULL(w.r.oie.z);
+				const float il = MIRT_PULL(w.r.invLen), lm = MIRT_PULL(w.limit);
+#undef MIRT_PULL
+				if (takes) {
+					uint32_t* at = base + (size_t)(g >> 8) * STK::stride + from;
+					w.cur = *at;
+					*at = BVH_DONE;
+					w.sp = 0;
+					// (all thirteen words are fetched: setting the reciprocals up again from o and d instead costs registers in the
+					// whole loop -- 12.2 against 14.3 Grays/s)
+					w.r.o = F3(ox, oy, oz); w.r.d = F3(dx, dy, dz); w.r.ie = F3(ix, iy, iz); w.r.oie = F3(px, py, pz);
+					w.r.invLen = il;
+					w.limit = lm;
+					grp = g & 63u;
+					w.tcull = __uint_as_float(s_cull[grp]);
+				}
+				if (robbed) grp = (grp + 256u) | ((grp & 63u) == lane ? 64u : 0u);
+				continue;
+			}
+		}
+		if (nNode * MIRT_NODE_WEIGHT >= nLeaf * MIRT_LEAF_WEIGHT) {
+			if (wantNode) w.node_step(S, stk);
+		}
+		else if (wantLeaf) {
+			const float t0 = w.tcull;
+			w.template leaf_step<false>(S, stk);
+			if (shared) {
+				if (w.limit >= 0.0f) { if (w.best.ref != REF_NONE) s_cull[grp & 63u] = 0u; }
+				else if (w.tcull < t0) atomicMin(s_cull + (grp & 63u), __float_as_uint(w.tcull));
+			}
+		}
+	}
+	if (shared) {
+		// fold the helpers' candidates into the owners'
+		const bool helper = (grp & 63u) != lane;
+		const unsigned long long key = ((unsigned long long)__float_as_uint(w.best.dist) << 32) | w.best.ref;
+		s_key[lane] = helper ? ~0ull : key;
+		s_cull[lane] = (!helper && w.needStrict) ? 1u : 0u;
+		if (helper && w.best.ref != REF_NONE) atomicMin(s_key + (grp & 63u), key);
+		const unsigned long long fin = s_key[grp & 63u];
+		const bool tie = w.best.ref != REF_NONE && (uint32_t)(key >> 32) == (uint32_t)(fin >> 32) && (uint32_t)key != (uint32_t)fin;
+		if (helper && (tie || w.needStrict)) s_cull[grp & 63u] = 1u;
+		if (!helper && tie) s_cull[lane] = 1u;
+		if (helper) {
+			w.best.ref = REF_NONE;
+			w.best.dist = __builtin_inff();
+			w.needStrict = false;
+		}
+		else {
+			w.best.dist = __uint_as_float((uint32_t)(fin >> 32));
+			w.best.ref = (uint32_t)fin;
+			w.needStrict = s_cull[lane] != 0u;
+		}
+	}
+}
+
 // ---- the tracing kernel: every ray of one depth in one launch ---------------------------------------------------------------
 // Per-path data (hit records, shadow answers, light sums) is indexed by pixel slot: a pixel has one path (main.cpp:176-201
 // recurses once per hit), so records are never moved.  What a depth works on is the list F.active[parity] of the slots
@@ -1165,9 +1295,9 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DFrame F, uint8_t* __restrict
 #define FRAME_SLOT_MASK ((1u << FRAME_SLOT_BITS) - 1u)
 #define FRAME_EMPTY 0xffffffffu
 
-template <int MODE, bool OVF>
+template <int MODE, bool OVF, bool SHARE>
 __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_FRAME_WAVES))) void k_frame(DScene S, DFrame F, uint8_t* __restrict__ out) {
-	__shared__ uint32_t s_stack[STACK_LDS * FRAME_BLOCK];
+	__shared__ __align__(8) uint32_t s_stack[STACK_LDS * FRAME_BLOCK];
 	__shared__ uint32_t s_list[FRAME_BLOCK / WAVE][128];
 	LdsStack<OVF, STACK_LDS, FRAME_BLOCK> stk;
 	stk.lds = s_stack + threadIdx.x;
@@ -1228,6 +1358,8 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 		w.cur = BVH_DONE;
 		w.best.ref = REF_NONE;
 		w.best.dist = __builtin_inff();
+		w.needStrict = false;
+		w.tcull = 0.0f;
 		if (!inBatch) {
 			if (nbuf < 64u && !pfirst) {
 				pbatch = nBatches;
@@ -1334,13 +1466,27 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 		const unsigned long long tRound = wall_clock64();
 #endif
 		if (walked) {
-			walk_wave<false, false>(S, w, stk);
+			// (the list holds fewer than 64 entries while rays are walked: its upper half is free)
+			if (SHARE) walk_wave_share(S, w, stk, s_stack, myList + 64, (unsigned long long*)s_stack);
+			else walk_wave<false, false>(S, w, stk);
 			// deferred check of the final answers; the rare ray that fails it is walked again, strictly
 			if (MODE == MODE_EXACT) {
 				const bool redo = walk && !w.verify(S);
 				if (__builtin_amdgcn_ballot_w64(redo)) {
+#if MIRT_TIMELINE
+					const unsigned long long tr0 = wall_clock64();
+#endif
 					if (redo) w.start(S, w.r.o, w.r.d, w.limit);
 					walk_wave<false, true>(S, w, stk);
+#if MIRT_TIMELINE
+					if (lane == 0) {
+						const unsigned long long dtr = wall_clock64() - tr0;
+						atomicAdd(S.dbg + 8, 1ull);
+						atomicAdd(S.dbg + 9, (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(redo)));
+						atomicAdd(S.dbg + 10, dtr);
+						atomicMax(S.dbg + 11, dtr);
+					}
+#endif
 				}
 			}
 		}

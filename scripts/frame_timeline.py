@@ -18,6 +18,7 @@ def q(s, k):
 with DeviceScene(flat, 0, lib=lib) as s:
     s.render(w, h)
     for k in range(140, 156): q(s, k)
+    for k in range(108, 114): q(s, k)
     _, st = s.render(w, h)
     t0 = (~q(s, 140)) & (2**64 - 1); tend = q(s, 141); ex0 = (~q(s, 142)) & (2**64 - 1); ex1 = q(s, 143)
     life, tail, waves, rounds, lanes = (q(s, k) for k in range(144, 149))
@@ -26,3 +27,6 @@ with DeviceScene(flat, 0, lib=lib) as s:
     print("waves %d, mean lifetime %.0f us, mean time after exhaustion %.0f us, rounds per wave %.1f, lanes per round %.1f" % (waves, us(life / waves), us(tail / waves), rounds / waves, lanes / max(1, rounds)))
     mx = [q(s, k) for k in range(149, 152)]; sm = [q(s, k) for k in range(152, 155)]
     print("longest round (camera, light, reflection) %s us; share of the summed round time %s" % ([round(us(x)) for x in mx], [round(x / max(1, sum(sm)), 3) for x in sm]))
+    r = [q(s, k) for k in range(108, 114)]
+    print("strict re-walks: %d rounds, %d lanes, summed %.0f us (%.3f of the summed round time), longest %.0f us; hand-overs %d, entries handed over %d" % (
+        r[0], r[1], us(r[2]), r[2] / max(1, sum(sm)), us(r[3]), r[4], r[5]))
