@@ -496,8 +496,10 @@ struct Walker {
 		STAT_LANE(S, 1); // node steps (lanes)
 		const uint4* nd = (const uint4*)S.bvh + (size_t)cur * 4;
 		// (The vector memory path takes about one cycle per lane and 16-byte request -- exp/ta/ta_bench.hip: 258 cycles for a
-		// wave's four requests per lane -- yet it is not what holds the walk up: a FIFTH request per node step, waited for,
-		// left the Stanford dragon's frame rate where it was.  A 48-byte node would buy nothing.)
+		// wave's four requests per lane, whether they hit in L1 or in L2 -- and with frames in flight the walk asks for 92 % of
+		// that rate; yet it is not what holds the walk up: a FIFTH request per node step, waited for, to the same line or to one
+		// 1 KB away, leaves the Stanford dragon's frame rate where it is (14.3 Grays/s, twice measured).  A 48-byte node would
+		// buy nothing.)
 		const uint4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
 		// scale/d per axis: the node stores signed power-of-two exponents
 		const float ax = __builtin_ldexpf(r.ie.x, (int)(q0.w << 24) >> 24);
@@ -819,6 +821,9 @@ __device__ __forceinline__ void walk_wave(const DScene& S, Walker<MODE, OVF>& w,
 #define MIRT_SHARE_MIN_FREE 16 // lanes without a walk before work is handed over
 #define MIRT_SHARE_GAP 4       // wave iterations between two hand-overs at least
 #endif
+#ifndef MIRT_SHARE_LEVELS
+#define MIRT_SHARE_LEVELS 4    // stack entries one lane hands over at a time at most (1..4)
+#endif
 #ifndef MIRT_SHARE_FIRST
 #define MIRT_SHARE_FIRST 4     // wave iterations before the first hand-over of a round
 #endif
@@ -850,7 +855,10 @@ __device__ __forceinline__ void walk_wave_share(const DScene& S, Walker<MODE, OV
 			const uint32_t nF = (uint32_t)__popcll(freeM), nG = (uint32_t)__popcll(giveM);
 			if (nF >= MIRT_SHARE_MIN_FREE / 2 && nG) {
 #if MIRT_TIMELINE
-				if (lane == 0) { atomicAdd(S.dbg + 12, 1ull); atomicAdd(S.dbg + 13, (unsigned long long)(nF < nG ? nF : nG)); }
+				{
+					const uint32_t nHold = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(c == -1 && w.best.ref != REF_NONE && (grp & 63u) == lane && !(grp & 64u)));
+					if (lane == 0) { atomicAdd(S.dbg + 12, 1ull); atomicAdd(S.dbg + 13, (unsigned long long)(nF < nG ? nF : nG)); atomicAdd(S.dbg + 14, (unsigned long long)nHold); atomicAdd(S.dbg + 15, (unsigned long long)nF); }
+				}
 #endif
 				gap = 0;
 				shared = true;
@@ -858,14 +866,24 @@ __device__ __forceinline__ void walk_wave_share(const DScene& S, Walker<MODE, OV
 				// the k-th giving lane's number goes to lane k (every lane sends to a lane of its own), the k-th free lane picks it up there
 				const uint32_t dest = gives ? rankG : nG + (uint32_t)__popcll(~giveM & ltMask);
 				const uint32_t packed = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)lane);
-				const uint32_t from = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rankF << 2), (int)packed);
-				const bool takes = free && rankF < nG;
-				const bool robbed = gives && rankG < nF;
+				// with more free lanes than giving ones, a giving lane serves up to MIRT_SHARE_LEVELS of them: its lowest entry, the
+				// one above it, ... as far as its stack goes
+				const uint32_t level = (uint32_t)(rankF >= nG) + (uint32_t)(rankF >= 2u * nG) + (uint32_t)(rankF >= 3u * nG);
+				const uint32_t from = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rankF - level * nG) << 2), (int)packed);
+				const bool asks = free && rankF < MIRT_SHARE_LEVELS * nG;
+				const uint32_t asked = (uint32_t)(nF > rankG) + (uint32_t)(nF > rankG + nG && MIRT_SHARE_LEVELS > 1) + (uint32_t)(nF > rankG + 2u * nG && MIRT_SHARE_LEVELS > 2) +
+				                       (uint32_t)(nF > rankG + 3u * nG && MIRT_SHARE_LEVELS > 3);
+				const uint32_t top = (uint32_t)w.sp < (uint32_t)STK::nlds ? (uint32_t)w.sp : (uint32_t)STK::nlds; // (only entries in LDS are handed over)
+				const uint32_t have = gives ? top - (grp >> 8) : 0u;
+				const uint32_t lost = asked < have ? asked : have; // entries this (giving) lane hands over
+				const bool robbed = gives && lost != 0u;
 				// the giving lanes bring the group's bound up to date first
 				if (robbed) atomicMin(s_cull + (grp & 63u), __float_as_uint(w.tcull));
-				const int src = (int)((takes ? from : lane) << 2);
+				const int src = (int)((asks ? from : lane) << 2);
 #define MIRT_PULL(x) __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(x)))
-				const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)grp);
+				const uint32_t gs = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(grp | (top << 16)));
+				const uint32_t g = gs & 0xffffu;
+				const bool takes = asks && (g >> 8) + level < (gs >> 16);
 				const float ox = MIRT_PULL(w.r.o.x), oy = MIRT_PULL(w.r.o.y), oz = MIRT_PULL(w.r.o.z);
 				const float dx = MIRT_PULL(w.r.d.x), dy = MIRT_PULL(w.r.d.y), dz = MIRT_PULL(w.r.d.z);
 				const float ix = MIRT_PULL(w.r.ie.x), iy = MIRT_PULL(w.r.ie.y), iz = MIRT_PULL(w.r.ie.z);
@@ -873,7 +891,7 @@ __device__ __forceinline__ void walk_wave_share(const DScene& S, Walker<MODE, OV
 				const float il = MIRT_PULL(w.r.invLen), lm = MIRT_PULL(w.limit);
 #undef MIRT_PULL
 				if (takes) {
-					uint32_t* at = base + (size_t)(g >> 8) * STK::stride + from;
+					uint32_t* at = base + (size_t)((g >> 8) + level) * STK::stride + from;
 					w.cur = *at;
 					*at = BVH_DONE;
 					w.sp = 0;
@@ -885,7 +903,7 @@ __device__ __forceinline__ void walk_wave_share(const DScene& S, Walker<MODE, OV
 					grp = g & 63u;
 					w.tcull = __uint_as_float(s_cull[grp]);
 				}
-				if (robbed) grp = (grp + 256u) | ((grp & 63u) == lane ? 64u : 0u);
+				if (robbed) grp = (grp + 256u * lost) | ((grp & 63u) == lane ? 64u : 0u);
 				continue;
 			}
 		}
