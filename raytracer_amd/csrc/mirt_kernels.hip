@@ -847,6 +847,14 @@ __device__ __forceinline__ void walk_wave_share(const DScene& S, Walker<MODE, OV
 		const bool wantNode = c >= 0, wantLeaf = c < -1;
 		const uint32_t nNode = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(wantNode)), nLeaf = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(wantLeaf));
 		if (nNode + nLeaf == 0u) break;
+#if MIRT_TIMELINE
+		{
+			// idle lanes of this iteration by kind: holding a hit of their own / owners that gave work away / free to help
+			const uint32_t nHold = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(c == -1 && (grp & 63u) == lane && w.best.ref != REF_NONE));
+			const uint32_t nLent = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(c == -1 && (grp & 64u) && w.best.ref == REF_NONE));
+			if (lane == 0) { atomicAdd(S.dbg + 8, (unsigned long long)nHold); atomicAdd(S.dbg + 9, (unsigned long long)nLent); atomicAdd(S.dbg + 10, (unsigned long long)(64u - nNode - nLeaf)); atomicAdd(S.dbg + 11, 1ull); }
+		}
+#endif
 		++gap;
 		if (64u - (nNode + nLeaf) >= MIRT_SHARE_MIN_FREE && gap >= MIRT_SHARE_GAP) {
 			const bool free = c == -1 && w.best.ref == REF_NONE && !w.needStrict && !(grp & 64u);
@@ -1491,20 +1499,8 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 			if (MODE == MODE_EXACT) {
 				const bool redo = walk && !w.verify(S);
 				if (__builtin_amdgcn_ballot_w64(redo)) {
-#if MIRT_TIMELINE
-					const unsigned long long tr0 = wall_clock64();
-#endif
 					if (redo) w.start(S, w.r.o, w.r.d, w.limit);
 					walk_wave<false, true>(S, w, stk);
-#if MIRT_TIMELINE
-					if (lane == 0) {
-						const unsigned long long dtr = wall_clock64() - tr0;
-						atomicAdd(S.dbg + 8, 1ull);
-						atomicAdd(S.dbg + 9, (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(redo)));
-						atomicAdd(S.dbg + 10, dtr);
-						atomicMax(S.dbg + 11, dtr);
-					}
-#endif
 				}
 			}
 		}

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic (a -DMIRT_TIMELINE=1 build of mirt_api.hip as exp/libmirt_timeline.so): where the time of ONE k_frame launch goes.
 Prints, in microseconds from the first wave's start: when the pixel slots ran out (first / last wave to notice), when the last
-wave ended, the mean wave lifetime and the mean time a wave spent after the slots had run out, rounds and lane use, the strict
-re-walks and the hand-overs of stack entries between lanes (the counters of the last line are atomics on one word each, and so
+wave ended, the mean wave lifetime and the mean time a wave spent after the slots had run out, rounds and lane use, the idle
+lanes by kind and the hand-overs of stack entries between lanes (the counters of the last line are atomics on one word each, and so
 many of them that this build's times are several times the library's: read its last line for the counts only)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,5 +30,5 @@ with DeviceScene(flat, 0, lib=lib) as s:
     mx = [q(s, k) for k in range(149, 152)]; sm = [q(s, k) for k in range(152, 155)]
     print("longest round (camera, light, reflection) %s us; share of the summed round time %s" % ([round(us(x)) for x in mx], [round(x / max(1, sum(sm)), 3) for x in sm]))
     r = [q(s, k) for k in range(108, 116)]
-    print("strict re-walks: %d rounds, %d lanes, summed %.0f us (%.3f of the summed round time), longest %.0f us; hand-overs %d, entries handed over %d, free lanes then %d, idle lanes holding a hit of their own then %d" % (
-        r[0], r[1], us(r[2]), r[2] / max(1, sum(sm)), us(r[3]), r[4], r[5], r[7], r[6]))
+    print("shared walks: %d wave iterations, idle lane slots %d of which %d hold a hit of their own and %d are owners that gave work away; hand-overs %d, entries handed over %d, free lanes then %d, idle lanes holding a hit then %d" % (
+        r[3], r[2], r[0], r[1], r[4], r[5], r[7], r[6]))
