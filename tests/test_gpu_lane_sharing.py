@@ -56,3 +56,22 @@ def test_big_frames_with_lane_sharing_equal_the_walk_of_the_reference_tree(size,
         if w * h <= 1920 * 1080:
             ref, _ = s.render(w, h, trace_mode=_capi.TRACE_REFWALK)
             assert np.array_equal(shared, ref)
+
+
+def test_cornell_and_ellipsoids_at_full_size_with_lane_sharing_forced(goldens, monkeypatch):
+    """Scenes the library would not pick the helping kernel for (few primitives, spheres and ellipsoids among them),
+    against the reference's own images at the benchmark sizes."""
+    from raytracer_amd import workloads
+    from raytracer_amd.device import DeviceScene
+    from raytracer_amd.scene import FlatScene
+    monkeypatch.setenv("MIRT_SHARE", "1")
+    g = goldens("c1_cornell")
+    with DeviceScene(FlatScene.from_text(workloads.cornell()), 0) as s:
+        img, st = s.render(640, 480)
+        assert np.array_equal(img, g["bgr"])
+        assert [st["primary_rays"], st["shadow_rays"], st["reflection_rays"]] == g["rays"].tolist()
+    g = goldens("c2_spheres")
+    with DeviceScene(FlatScene.from_text(workloads.spheres()), 0) as s:
+        img, st = s.render(1920, 1080)
+        assert np.array_equal(img, g["bgr"])
+        assert [st["primary_rays"], st["shadow_rays"], st["reflection_rays"]] == g["rays"].tolist()
