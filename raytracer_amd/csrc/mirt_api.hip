@@ -193,6 +193,8 @@ struct CopyBack {
 	int nBands = 0;
 	std::atomic<int> next{0};
 	std::atomic<bool> failed{false};
+	bool clean[MAX_BANDS];    // the band holds nothing but the zeros it was cleared to: it is not fetched, the destination is zeroed
+	uint32_t* flags = nullptr; // page-locked: the frame's notes of the parts it wrote (CTR_NPARTS words)
 
 	CopyBack(int dev, int nThreads) : device(dev) {
 		for (int i = 0; i < nThreads; ++i) workers.emplace_back([this]() { loop(); });
@@ -203,6 +205,7 @@ struct CopyBack {
 		for (auto& t : workers) t.join();
 		for (int i = 0; i < nEv; ++i) (void)hipEventDestroy(ev[i]);
 		if (staging) (void)hipHostFree(staging);
+		if (flags) (void)hipHostFree(flags);
 	}
 	// A band is moved in PIECES quarters, whoever gets them: wait for the band's DMA, move the quarter.  (One thread per whole
 	// band leaves the last band's 2 MB to a single memcpy after the last DMA has ended: 0.2 ms at the end of every frame.)
@@ -212,9 +215,10 @@ struct CopyBack {
 			const int j = next.fetch_add(1);
 			if (j >= nBands * PIECES) return;
 			const int k = j / PIECES, q = j % PIECES;
-			if (hipEventSynchronize(ev[k]) != hipSuccess) { failed = true; continue; }
 			const size_t at = (size_t)k * band, n = at + band <= bytes ? band : bytes - at;
 			const size_t piece = ((n + PIECES - 1) / PIECES + 63) & ~(size_t)63, a = (size_t)q * piece;
+			if (clean[k]) { if (a < n) memset(dst + at + a, 0, a + piece <= n ? piece : n - a); continue; }
+			if (hipEventSynchronize(ev[k]) != hipSuccess) { failed = true; continue; }
 			if (a < n) memcpy(dst + at + a, (const uint8_t*)staging + at + a, a + piece <= n ? piece : n - a);
 		}
 	}
@@ -233,8 +237,12 @@ struct CopyBack {
 			cvDone.notify_one();
 		}
 	}
-	// false: staging or events could not be had (nothing was copied)
-	bool run(const void* dsrc, uint8_t* hdst, size_t n, hipStream_t st) {
+	// false: staging or events could not be had (nothing was copied).
+	// dNotes != NULL: CTR_NPARTS words on the device, written by the frame that precedes this call on the stream; word i != 0
+	// says that bytes [i << shift, (i + 1) << shift) of the output hold something else than the zeros they were cleared to.
+	// Bands without such a part are not fetched at all.  The price is that the copies cannot be queued behind the frame in
+	// advance: the host waits for the frame's end and its notes (128 bytes) first.
+	bool run(const void* dsrc, uint8_t* hdst, size_t n, hipStream_t st, const uint32_t* dNotes = nullptr, uint32_t shift = 0) {
 		if (n > stagingBytes) {
 			if (staging) (void)hipHostFree(staging);
 			staging = nullptr;
@@ -251,7 +259,19 @@ struct CopyBack {
 		dst = hdst;
 		bytes = n;
 		failed = false;
+		for (int k = 0; k < nBands; ++k) clean[k] = false;
+		if (dNotes) {
+			if (!flags && hipHostMalloc((void**)&flags, CTR_NPARTS * 4, hipHostMallocDefault) != hipSuccess) { flags = nullptr; return false; }
+			if (hipMemcpyAsync(flags, dNotes, CTR_NPARTS * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return false;
+			for (int k = 0; k < nBands; ++k) {
+				const size_t at = (size_t)k * band, len = at + band <= n ? band : n - at;
+				bool any = false;
+				for (size_t i = at >> shift; i <= (at + len - 1) >> shift; ++i) any = any || i >= CTR_NPARTS || flags[i] != 0;
+				clean[k] = !any;
+			}
+		}
 		for (int k = 0; k < nBands; ++k) {
+			if (clean[k]) continue;
 			const size_t at = (size_t)k * band, len = at + band <= n ? band : n - at;
 			if (hipMemcpyAsync((uint8_t*)staging + at, (const uint8_t*)dsrc + at, len, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
 			if (hipEventRecord(ev[k], st) != hipSuccess) return false;
@@ -1916,10 +1936,23 @@ int mirt_render(mirt_scene* s, const mirt_render_params* p, uint8_t* bgr_out, mi
 	if (!c) return MIRT_E_INVALID;
 	if ((e = c->ws.out.ensure(bytes))) return e;
 	if ((e = render_async(s, p, c->ws.out.p, bytes, s->stream, !whole))) return e;
+	// Behind the frame a small launch notes which parts of the image hold anything but black (k_note_parts, in words of the
+	// frame's counter block that the frame itself does not use), and the copy back fetches only the bands with such a part.
+	// MIRT_COPY_SPARSE=0: every band is fetched, queued behind the frame in advance.
+	const char* sparseEnv = getenv("MIRT_COPY_SPARSE"); // (read per call: tests switch it)
+	const bool sparse = !(sparseEnv && *sparseEnv == '0');
+	const bool staged = whole && s->copyThreads > 0 && bytes >= (4u << 20);
+	uint32_t shift = 20;
+	while ((bytes >> shift) >= CTR_NPARTS) ++shift;
+	const bool noted = staged && sparse;
+	if (noted) {
+		const uint32_t nParts = (uint32_t)((bytes + ((size_t)1 << shift) - 1) >> shift), blocksPerPart = 64;
+		hipLaunchKernelGGL(k_note_parts, dim3(nParts * blocksPerPart), dim3(BLOCK), 0, s->stream, (const uint8_t*)c->ws.out.p, bytes, shift, blocksPerPart, (uint32_t*)c->ws.counters.p + CTR_PARTS);
+	}
 	if (whole) {
-		if (s->copyThreads > 0 && bytes >= (4u << 20)) {
+		if (staged) {
 			if (!s->copyBack) s->copyBack = new (std::nothrow) CopyBack(s->device, s->copyThreads);
-			if (s->copyBack && s->copyBack->run(c->ws.out.p, bgr_out, bytes, s->stream)) {
+			if (s->copyBack && s->copyBack->run(c->ws.out.p, bgr_out, bytes, s->stream, noted ? (const uint32_t*)c->ws.counters.p + CTR_PARTS : nullptr, shift)) {
 				if (stats) return read_stats(s, s->stream, stats);
 				return MIRT_OK;
 			}

@@ -131,5 +131,8 @@ struct DFrame {
 #define CTR_F_HITS_LAST 162     // hits at the last depth (they spawn no reflection ray)
 #define CTR_F_SHADOW_TRACED 163 // shadow queries that were walked
 #define CTR_F_REFL_SKIPPED 164  // reflection rays with weight zero that MIRT_TRACE_FAST did not trace
+// both paths: what k_note_parts finds in the finished image (words no launch of a frame uses)
+#define CTR_PARTS 192           // 32 words: 1 = that part of the output holds something else than zeros
+#define CTR_NPARTS 32
 #define CTR_COUNT 256
 #define FRAME_SLOT_BITS 27    // k_frame packs slot and depth into one word: fewer than 2^27 slots, depth <= 31
