@@ -420,6 +420,11 @@ __device__ __forceinline__ uint32_t membership(const DScene& S, const RayCtx& r,
 template <bool OVF, int NLDS = STACK_LDS, int STRIDE = BLOCK>
 struct LdsStack {
 	static constexpr int stride = STRIDE, nlds = NLDS;
+	// (The frame kernel has two speeds, 14.3 and 12.3 Grays/s on the Stanford dragon, and small changes anywhere in it flip it
+	// to the slow one: then the compiler has picked THIS pointer for spilling and every push and pop of the walk waits for a
+	// scratch load.  Check `make asm` for scratch loads in the walk loop after touching the kernel.  Keeping only the block's
+	// base here and adding threadIdx.x at every access, behind an empty asm so that the sum is not hoisted and spilled
+	// itself, makes the slow form impossible but costs the dragon 1 % (ellipsoids +3 %); not adopted.)
 	uint32_t* lds;   // this thread's column
 	uint32_t* ovf;   // [level][global thread], this thread's column
 	uint32_t ovfStride;
