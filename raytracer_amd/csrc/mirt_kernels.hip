@@ -424,7 +424,7 @@ struct LdsStack {
 	// to the slow one: then the compiler has picked THIS pointer for spilling and every push and pop of the walk waits for a
 	// scratch load.  Check `make asm` for scratch loads in the walk loop after touching the kernel.  Keeping only the block's
 	// base here and adding threadIdx.x at every access, behind an empty asm so that the sum is not hoisted and spilled
-	// itself, makes the slow form impossible but costs the dragon 1 % (ellipsoids +3 %); not adopted.)
+	// itself, makes the slow form impossible but costs the dragon 0.5-1 % and gives the other scenes nothing reliable; not adopted.)
 	uint32_t* lds;   // this thread's column
 	uint32_t* ovf;   // [level][global thread], this thread's column
 	uint32_t ovfStride;
