@@ -266,6 +266,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the caller keeps `depth` frames in flight and says so: without it the first frames after every fence are launched as
+    # if they had the GPU to themselves (they find nothing in flight), and the frames behind them wait
+    scene.set_frames_in_flight(depth)
     # set-up, like the scene upload: the library allocates a stream's workspace (2.6 GB at 4K) at the stream's first frame
     for _ in range(depth):
         step()
@@ -282,6 +285,7 @@ def main():
     stream = streams[(frame_no[0] - 1) % depth].cuda_stream
     local = locals_[(frame_no[0] - 1) % depth]
     st = scene.stats(stream)
+    scene.set_frames_in_flight(1)  # from here on frames are rendered one at a time
     # Self-check of the timed mode: the last frame of EVERY stream (rendered with the other streams' frames in flight)
     # must equal a frame rendered alone on a stream of its own, byte for byte; no figure is printed otherwise.
     check_stream = torch.cuda.Stream()

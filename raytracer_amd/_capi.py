@@ -93,6 +93,7 @@ SYMBOLS = [
     ("mirt_tile_buffer_bytes", C.c_size_t, [C.POINTER(RenderParams)]),
     ("mirt_render_device_noalloc", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_size_t, C.c_void_p]),
     ("mirt_release_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("mirt_set_frames_in_flight", C.c_int, [C.c_void_p, C.c_uint32]),
     ("mirt_get_stats", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     ("mirt_scene_query", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("mirt_set_profiling", C.c_int, [C.c_void_p, C.c_int]),

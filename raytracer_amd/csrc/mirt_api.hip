@@ -311,6 +311,7 @@ struct mirt_scene {
 	// (hipHostRegister) is refused on the machines this was developed on.  MIRT_COPY_THREADS=0 goes back to the plain copy.
 	CopyBack* copyBack = nullptr;
 	int copyThreads = 6;
+	uint32_t framesHint = 0;  // frames the caller says it keeps in flight (mirt_set_frames_in_flight); 0, 1: not said
 	bool singleLaunch = true; // frames run as one launch (k_frame) where that kernel applies; MIRT_SINGLE_LAUNCH=0: one launch per depth
 };
 
@@ -1053,6 +1054,7 @@ int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 	for (FrameCtx* o : s->ctxs)
 		if (o != c && o->lastValid && hipEventQuery(o->ev1) == hipErrorNotReady) ++others;
 	(void)hipGetLastError(); // (hipErrorNotReady is an answer, not a failure)
+	if (s->framesHint > 1 && others < (int)s->framesHint - 1) others = (int)s->framesHint - 1;
 	HIPCHK(hipEventRecord(c->ev0, st));
 	if ((e = enqueue_frame(s, c, p, g, tileW, tileH, packed, single, mem, d_out, need, st, others))) return e;
 	HIPCHK(hipEventRecord(c->ev1, st));
@@ -1889,6 +1891,12 @@ int mirt_scene_query(mirt_scene* s, uint32_t what, uint64_t* v) {
 		}
 		return fail(MIRT_E_INVALID, "unknown query %u", what);
 	}
+	return MIRT_OK;
+}
+
+int mirt_set_frames_in_flight(mirt_scene* s, uint32_t n) {
+	if (!s) return fail(MIRT_E_INVALID, "scene handle is NULL");
+	s->framesHint = n;
 	return MIRT_OK;
 }
 

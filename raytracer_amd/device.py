@@ -93,6 +93,10 @@ class DeviceScene:
     def release_stream(self, stream_ptr):
         _check(self.lib, self.lib.mirt_release_stream(self.h, C.c_void_p(stream_ptr)))
 
+    def set_frames_in_flight(self, n):
+        """Hint: the caller keeps n frames of this scene in flight (one per stream); 0 or 1 = sized by what is found in flight."""
+        _check(self.lib, self.lib.mirt_set_frames_in_flight(self.h, int(n)))
+
     def stats(self, stream_ptr=0):
         st = Stats()
         _check(self.lib, self.lib.mirt_get_stats(self.h, C.c_void_p(stream_ptr), C.byref(st)))

@@ -77,6 +77,8 @@ def test_frames_in_flight_on_eight_streams_are_byte_exact(which, size, flat_scen
         streams = [hip.stream() for _ in range(N_STREAMS)]
         bufs = [[hip.alloc(nbytes) for _ in range(FRAMES_PER_STREAM)] for _ in range(N_STREAMS)]
         p = _capi.make_params(w, h)
+        if which == "default":
+            s.set_frames_in_flight(N_STREAMS)    # the caller's hint: every frame is launched as one of eight, the first ones too
         for f in range(FRAMES_PER_STREAM):       # round-robin: every stream has a frame queued before any gets its next
             for k, st in enumerate(streams):
                 s.render_device(p, bufs[k][f], nbytes, st)
@@ -87,6 +89,7 @@ def test_frames_in_flight_on_eight_streams_are_byte_exact(which, size, flat_scen
             for f in range(FRAMES_PER_STREAM):
                 got = hip.to_host(bufs[k][f], nbytes).reshape(h, w, 3)
                 assert np.array_equal(got, want), "stream %d frame %d: %d bytes differ" % (k, f, int((got != want).sum()))
+        s.set_frames_in_flight(0)
         # a stream's workspace can be handed back, and the stream used again afterwards
         s.release_stream(streams[0])
         s.render_device(p, bufs[0][0], nbytes, streams[0])
