@@ -44,9 +44,34 @@ def render_cached(cache_path, out_path, size=None, features=_capi.F_ALL, debug=_
     return img, st, lines
 
 
+def text_digest(scene_path):
+    """Two words that identify the scene text a cache was made from (they travel in the cache file's user words)."""
+    import hashlib
+    with open(scene_path, "rb") as f:
+        d = hashlib.sha256(f.read()).digest()
+    return int.from_bytes(d[:4], "little"), int.from_bytes(d[4:8], "little")
+
+
+def cache_matches(cache_path, scene_path):
+    """Was this cache file written from this scene text?  A scene file that cannot be read leaves the cache in charge (that
+    is what the cache is for: rendering without the text); a readable one whose digest differs means the text was edited or
+    the cache belongs to another scene, and the scene is built again."""
+    import struct
+    if not os.path.exists(scene_path):
+        return True
+    with open(cache_path, "rb") as f:
+        head = f.read(8 + 4 * 4 + 4 * 4)
+    if len(head) < 40:
+        return False
+    user = struct.unpack_from("<4I", head, 24)
+    return (user[2], user[3]) == text_digest(scene_path)
+
+
 def render_file(scene_path, out_path=None, size=None, features=_capi.F_ALL, debug=_capi.DEBUG_NONE, device=0, report=True, cache=None):
     if cache and os.path.exists(cache):
-        return render_cached(cache, out_path or os.path.splitext(os.path.basename(scene_path))[0] + ".png", size, features, debug, device)
+        if cache_matches(cache, scene_path):
+            return render_cached(cache, out_path or os.path.splitext(os.path.basename(scene_path))[0] + ".png", size, features, debug, device)
+        print("%s was not written from %s as it is now: building the scene again" % (cache, scene_path))
     t0 = time.perf_counter()
     flat = FlatScene.from_file(scene_path)
     t_load = time.perf_counter() - t0
@@ -57,7 +82,7 @@ def render_file(scene_path, out_path=None, size=None, features=_capi.F_ALL, debu
     with DeviceScene(flat, device) as s:
         t_upload = time.perf_counter() - t0
         if cache:
-            s.save(cache, user=(flat.width, flat.height, 0, 0))
+            s.save(cache, user=(flat.width, flat.height) + text_digest(scene_path))
         img, st = s.render(flat.width, flat.height, features=features, debug=debug)
     t0 = time.perf_counter()
     write_png(out_path, img)

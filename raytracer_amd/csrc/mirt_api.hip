@@ -1747,9 +1747,18 @@ int mirt_scene_load(const char* path, int device, mirt_scene** out, uint32_t use
 		mirt_scene_destroy(s);
 		return fail(MIRT_E_INVALID, "%s: %s", path, why);
 	}
-	s->nested = m.nested != 0; s->bvhDepth = m.bvhDepth; s->deepBvh = m.deepBvh != 0; s->nLights = m.nLights; s->maxDepth = m.maxDepth;
-	s->wideDepth = m.wideDepth; s->refillMin = m.refillMin; s->ovfLevels = m.ovfLevels;
+	s->nested = m.nested != 0; s->bvhDepth = m.bvhDepth; s->nLights = m.nLights; s->maxDepth = m.maxDepth;
+	s->wideDepth = m.wideDepth; s->refillMin = m.refillMin;
 	memcpy(s->diag, m.diag, sizeof m.diag);
+	// How much of the traversal stack lies beyond LDS depends on THIS build's STACK_LDS, not on the build that wrote the
+	// file: derived again from the stack need of the hierarchy (diag[6]), exactly as mirt_scene_create does.
+	{
+		const uint32_t ldsEntries = STACK_LDS_REFILL < STACK_LDS ? STACK_LDS_REFILL : STACK_LDS;
+		const uint32_t stackNeed = s->diag[6];
+		if (stackNeed == 0 || stackNeed > 4096) { mirt_scene_destroy(s); return fail(MIRT_E_INVALID, "%s: inconsistent header (traversal stack need %u)", path, stackNeed); }
+		s->deepBvh = stackNeed > ldsEntries;
+		s->ovfLevels = s->deepBvh ? stackNeed - ldsEntries : 0u;
+	}
 	s->ovfStride = (uint32_t)s->numCUs * GRID_BLOCKS_PER_CU * BLOCK;
 	if (const char* env = getenv("MIRT_SINGLE_LAUNCH")) s->singleLaunch = atoi(env) != 0;
 	if (const char* env = getenv("MIRT_COPY_THREADS")) { const int v = atoi(env); if (v >= 0 && v <= 32) s->copyThreads = v; }
@@ -1952,7 +1961,9 @@ int mirt_render(mirt_scene* s, const mirt_render_params* p, uint8_t* bgr_out, mi
 	const bool staged = whole && s->copyThreads > 0 && bytes >= (4u << 20);
 	uint32_t shift = 20;
 	while ((bytes >> shift) >= CTR_NPARTS) ++shift;
-	const bool noted = staged && sparse;
+	// (only a frame that really ran has a counter block to note in: with maxdepth < 0 the image is a plain clear and no
+	// workspace exists)
+	const bool noted = staged && sparse && c->lastValid && c->ws.counters.p != nullptr;
 	if (noted) {
 		const uint32_t nParts = (uint32_t)((bytes + ((size_t)1 << shift) - 1) >> shift), blocksPerPart = 64;
 		hipLaunchKernelGGL(k_note_parts, dim3(nParts * blocksPerPart), dim3(BLOCK), 0, s->stream, (const uint8_t*)c->ws.out.p, bytes, shift, blocksPerPart, (uint32_t*)c->ws.counters.p + CTR_PARTS);

@@ -59,3 +59,15 @@ def test_device_powf_is_the_reference_builds_powf(goldens):
     nan = np.isnan(want)
     assert np.array_equal(np.isnan(got), nan)
     assert np.array_equal(got[~nan].view(np.uint32), want[~nan].view(np.uint32))
+
+
+def test_maxdepth_below_zero_at_a_size_that_takes_the_staged_copy():
+    """With maxdepth < 0 a frame is a plain clear and no workspace exists (main.cpp:177,199: Color() for every pixel).  At
+    1920x1080 the image is large enough for mirt_render's banded copy back, which must not look for a frame's notes then."""
+    from raytracer_amd.device import DeviceScene
+    fs = FlatScene.from_text("size 1920 1080\nmaxdepth -1\n" + HEAD + "point 0 2 2 1 1 1\n" + TRI + "tri 0 1 2\n")
+    with DeviceScene(fs, 0) as s:
+        img = np.full((1080, 1920, 3), 7, np.uint8)
+        _, st = s.render(out=img)
+        assert not img.any()
+        assert st["primary_rays"] == 1920 * 1080 and st["shadow_rays"] == 0 and st["reflection_rays"] == 0

@@ -102,3 +102,55 @@ def test_scene_preparation_does_not_depend_on_the_thread_count(tmp_path):
         header = 8 + 4 * 4 + 4 * 4 + 8
         blobs.append(raw[header + dscene_bytes:])   # SceneMeta and the eleven arrays
     assert len(blobs[0]) == len(blobs[1]) and blobs[0] == blobs[1]
+
+
+def test_cache_written_by_one_build_loads_into_a_build_with_a_smaller_lds_stack(flat_scenes, goldens, tmp_path):
+    """How many traversal-stack entries lie beyond LDS is a property of the build that RENDERS, not of the build that wrote the
+    file: a cache from the default library (18 entries in LDS) must come back with the overflow area in place in the
+    library built with 2."""
+    import os
+    from raytracer_amd.device import DeviceScene
+    small = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracer_amd", "libmirt_smallstack.so")
+    if not os.path.exists(small):
+        pytest.skip("libmirt_smallstack.so not built")
+    lib = _capi.load_library(small)
+    g = goldens("scene7")
+    w, h = int(g["width"]), int(g["height"])
+    path = str(tmp_path / "scene7.mirt")
+    with DeviceScene(flat_scenes("scene7"), 0) as s:
+        s.save(path)
+    cached, _ = DeviceScene.load(path, 0, lib=lib)
+    with cached as s:
+        img, _ = s.render(w, h)
+        assert np.array_equal(img, g["bgr_f15"])
+        ids, dist = s.trace_primary_ids(w, h)
+        assert np.array_equal(ids, g["prim_id"]) and np.array_equal(bits(dist), bits(g["dist"]))
+    # and the other way round
+    with DeviceScene(flat_scenes("scene7"), 0, lib=lib) as s:
+        s.save(path)
+    cached, _ = DeviceScene.load(path, 0)
+    with cached as s:
+        img, _ = s.render(w, h)
+        assert np.array_equal(img, g["bgr_f15"])
+
+
+def test_command_line_rebuilds_when_the_scene_text_has_changed(tmp_path, monkeypatch):
+    import os
+    import shutil
+    from raytracer_amd.__main__ import render_file
+    monkeypatch.chdir(tmp_path)
+    src = os.path.join(os.path.dirname(os.path.dirname(__file__)), "raytracer_amd", "data", "scenes", "scene6.test")
+    scene = str(tmp_path / "scene.test")
+    shutil.copy(src, scene)
+    cache = str(tmp_path / "scene.mirt")
+    a, _, _ = render_file(scene, out_path=str(tmp_path / "a.png"), cache=cache, size=(160, 120))
+    b, _, lines = render_file(scene, out_path=str(tmp_path / "b.png"), cache=cache, size=(160, 120))
+    assert np.array_equal(a, b) and any("Scene cache" in l for l in lines)
+    text = open(scene).read().replace("maxdepth 5", "maxdepth 0")
+    assert text != open(src).read()
+    open(scene, "w").write(text)
+    c, _, lines = render_file(scene, out_path=str(tmp_path / "c.png"), cache=cache, size=(160, 120))
+    assert not any("Scene cache" in l for l in lines)          # built from the text again
+    assert not np.array_equal(a, c)                              # and it is the edited scene that was rendered
+    d, _, lines = render_file(scene, out_path=str(tmp_path / "d.png"), cache=cache, size=(160, 120))
+    assert np.array_equal(c, d) and any("Scene cache" in l for l in lines)  # the cache was written anew
