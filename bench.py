@@ -120,59 +120,88 @@ def device_walk_counts(flat, dev_index, width, height, trace_mode):
     return c
 
 
-def roofline(scene, flat, args, width, height, trace_mode, rays, vis, srays, kern, kern_alone, step_s):
-    """HBM roofline of the dominant kernel (the launches that walk the scene).
+def newest_profile(name):
+    """profiles/rNN/<name> of the latest round that holds it, or None."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", name)))
+    return found[-1] if found else None
 
-    achieved = ALGORITHMIC bytes of the DEVICE's walk per frame / duration of those launches for a frame rendered ALONE
-    (HIP events on the launch stream).  The bytes are what the lanes ask the memory system for, counted by the statistics
-    build on the same frame: 64 B per node step (one four-child node), 64 B per triangle test (144 B per sphere test), 32 B
-    per triangle test that falls back to the reference's own inside test, 16 + 32 B per leaf box of a membership check,
-    4 B per traversal-stack push beyond LDS and 4 B per pop, and per hit: 48 B record written and read once per light
-    set-up, per light shading and per reflection set-up, a 16-B light sum read and written per light and read once more
-    by the fold, 64 B of material; 3 B per pixel cleared, 3 B per pixel written.  The Dragon is cache resident (HBM
-    `traffic` is a small fraction of this), so this is a demand figure against the HBM peak, not a claim of HBM use; the
-    kernel's real limiter, VALU issue under divergence, is priced in `valu_issue` from the PMC pass under profiles/.
-    The reference's exhaustive walk priced the same way (box tests x 32 B + primitive tests x 40 B + 32 B ray state,
-    visit counts from the oracle on the CPU sample) is kept beside it as `reference_walk`."""
+
+def roofline(scene, flat, args, width, height, trace_mode, rays, vis, srays, kern, kern_alone, step_s, clock_hz, n_simds):
+    """Roofline of the dominant kernel (the launches that walk the scene; with k_frame: one launch = one frame).
+
+    Which roof: the scenes that live in the caches (everything but the 10 M-triangle grid) fetch a small fraction of the HBM
+    peak, so their bound is VALU ISSUE: achieved = wave-level VALU instructions of a frame (SQ_INSTS_VALU, rocprofv3 --pmc
+    pass over the same frame, profiles/rNN/pmc_<workload>.json) x 2 issue cycles (a wave64 instruction on a 32-lane SIMD)
+    / ms_per_step, against peak = SIMDs x the shader clock MEASURED under this run's load (mirt_clock_probe: shader-cycle
+    counter against the 100 MHz counter while the frames are in flight).  Two cycles is the floor per instruction (packed,
+    transcendental and double-precision ones take more), so `frac` is a lower bound of the issue time.
+    The grid reads memory: bound hbm, achieved = HBM bytes of the frame's launches from the counters (FETCH_SIZE x 2 for
+    gfx950 + WRITE_SIZE) / their summed duration for a frame alone (HIP events on the launch stream).
+    Side figures, labelled: `hbm` = counter bytes per frame over ms_per_step against the 8 TB/s peak; `hbm_demand` = the
+    bytes the lanes ASK the memory system for (statistics build: 64 B per node step, 64 B per triangle test, 144 B per sphere
+    test, 32 B per fallback to the reference's inside test, 16 + 32 B per leaf box of a membership check, 8 B per stack entry
+    beyond LDS; per hit 48 B of record per set-up and light, 16-B light sums, 64 B of material; 3 B per pixel cleared and
+    written) -- served mostly by L1/L2/MALL, NOT a bound; `reference_walk` = what the reference's exhaustive walk would need."""
     nl = int(flat.lights.shape[0])
     tri = flat.tri_verts.shape[0] >= flat.spheres.shape[0]
     walk_kinds = ("primary", "trace", "shade", "frame")
     ms_alone = sum(kern_alone[k]["ms_per_frame"] for k in walk_kinds if k in kern_alone)
     ms_pipe = sum(kern[k]["ms_per_frame"] for k in walk_kinds if k in kern)
     n_launch = sum(kern_alone[k]["launches_per_frame"] for k in walk_kinds if k in kern_alone)
+    pmc = None
+    ppath = newest_profile("pmc_%s.json" % args.workload)
+    if ppath and (width, height) == WORKLOADS[args.workload][1]:
+        pmc = json.load(open(ppath))
+    hbm_bound = args.workload == "grid"
+    out = {"kernel": "%d launch(es) per frame that walk the scene (%s)" % (n_launch, ", ".join(k for k in walk_kinds if k in kern_alone)),
+           "launch_ms_alone": ms_alone, "launch_ms_in_pipeline": ms_pipe,
+           "shader_clock_hz": clock_hz, "simds": n_simds,
+           "clock_note": "shader clock measured in this run while frames were in flight (mirt_clock_probe: s_memtime ticks / s_memrealtime ticks x 100 MHz)"}
+    traffic = pmc.get("hbm_bytes_per_frame") if pmc else None
+    out["traffic"] = traffic
+    if pmc:
+        out["counters_from"] = os.path.relpath(ppath, ROOT)
+        out["traffic_note"] = "HBM bytes of one frame: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950: it tallies 128-B requests at 64 B) + WRITE_SIZE, KB x 1024, separate passes"
+    if hbm_bound:
+        out.update({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s"})
+        if traffic:
+            out["achieved"] = traffic / (ms_alone * 1e-3) / 1e9
+            out["frac"] = out["achieved"] / HBM_PEAK_GBS
+        else:
+            out.update({"achieved": None, "frac": None, "note": "no counter pass for this workload under profiles/"})
+    else:
+        peak = n_simds * clock_hz / 1e9 if clock_hz else None
+        out.update({"bound": "valu issue", "peak": peak, "unit": "Gcycle/s"})
+        if pmc and pmc.get("valu_insts_per_frame") and peak:
+            cyc = 2.0
+            out["achieved"] = pmc["valu_insts_per_frame"] * cyc / step_s / 1e9
+            out["frac"] = out["achieved"] / peak
+            out["frac_alone"] = pmc["valu_insts_per_frame"] * cyc / (ms_alone * 1e-3) / 1e9 / peak
+            out["valu_insts_per_frame"] = pmc["valu_insts_per_frame"]
+            out["cycles_per_inst"] = cyc
+            if pmc.get("valu_active_quad_cycles"):
+                # how long an instruction occupies ITS wave (SQ_ACTIVE_INST_VALU counts per wave, in quad-cycles): about 4
+                # cycles, while the SIMD starts another wave's instruction every 2 -- waves overlap, so this is no busy figure
+                out["valu_wave_cycles_per_inst"] = pmc["valu_active_quad_cycles"] * 4.0 / pmc["valu_insts_per_frame"]
+            out["lane_utilisation"] = pmc.get("valu_lane_util")
+            out["wait_frac"] = pmc.get("wait_frac")
+        else:
+            out.update({"achieved": None, "frac": None, "note": "no counter pass for this workload under profiles/ (or no clock reading)"})
+    if traffic:
+        out["hbm"] = {"bytes_per_frame": traffic, "GBs_per_step": traffic / step_s / 1e9, "utilisation_per_step": traffic / step_s / 1e9 / HBM_PEAK_GBS,
+                      "GBs_alone": traffic / (ms_alone * 1e-3) / 1e9, "l2_hit": pmc.get("l2_hit")}
     c = device_walk_counts(flat, scene.device, width, height, trace_mode)
-    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s"}
     if c:
         hits = c["hits"]
         b = (64.0 * c["node_steps"] + (64.0 if tri else 144.0) * c["primitive_tests"] + 32.0 * c["triangle_fallbacks"]
              + 16.0 * c["membership_checks"] + 32.0 * c["membership_boxes"] + 8.0 * c["stack_pushes_overflow"]
              + hits * (48.0 + 16.0 + 64.0 + nl * (48.0 + 48.0 + 32.0) + 48.0 + 16.0 + 16.0)
              + 3.0 * width * height + 3.0 * float(rays[0]))
-        out.update({"achieved": b / (ms_alone * 1e-3) / 1e9, "frac": b / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "algorithmic_bytes_per_frame": b, "device_walk_counts": c,
-                    "per_ray": {"node_steps": c["node_steps"] / float(rays[0] + rays[3] + rays[4]), "primitive_tests": c["primitive_tests"] / float(rays[0] + rays[3] + rays[4])}})
-    else:
-        out.update({"achieved": None, "frac": None, "note_counts": "raytracer_amd/libmirt_stats.so not built: no device-walk counts"})
-    out["kernel"] = "%d launch(es) per frame that walk the scene (%s)" % (n_launch, ", ".join(k for k in walk_kinds if k in kern_alone))
-    out["launch_ms_alone"] = ms_alone
-    out["launch_ms_in_pipeline"] = ms_pipe
-    # HBM traffic, VALU issue and lane use come from rocprofv3 --pmc passes (they cannot be read from inside this process):
-    # scripts/profile_round.sh runs them over one frame of this workload and leaves the summary under profiles/
-    out["traffic"] = None
-    ppath = os.path.join(ROOT, "profiles", "r02", "pmc_frame.json")
-    if args.workload == "dragon" and (width, height) == (3840, 2160) and os.path.exists(ppath):
-        pmc = json.load(open(ppath))
-        out["traffic"] = pmc.get("hbm_bytes_per_frame")
-        out["traffic_note"] = "HBM bytes of one frame alone: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950: it tallies 128-B requests at 64 B) + WRITE_SIZE, KB x 1024, separate passes; profiles/r02/pmc_frame.json"
-        if pmc.get("valu_insts_per_frame") and pmc.get("kernel_ms"):
-            simds, clock = 1024, 2.4e9
-            # gfx950's SIMDs are 32 lanes wide: with several waves resident a SIMD issues one wave64 VALU instruction per 2 cycles
-            cyc = 2
-            out["valu_issue"] = {"bound": "valu issue", "insts_per_frame": pmc["valu_insts_per_frame"], "cycles_per_inst": cyc, "simds": simds, "clock_hz": clock,
-                                 "frac_alone": pmc["valu_insts_per_frame"] * cyc / (simds * clock * ms_alone * 1e-3),
-                                 "frac_per_step": pmc["valu_insts_per_frame"] * cyc / (simds * clock * step_s),
-                                 "lane_utilisation": pmc.get("valu_lane_util"), "wait_frac": pmc.get("wait_frac"),
-                                 "note": "wave-level VALU instructions of one frame (SQ_INSTS_VALU) x 2 issue cycles (SIMD-32) over 1024 SIMDs x 2.4 GHz x time: over the launch of a frame alone, and over ms_per_step with frames in flight; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES"}
+        out["hbm_demand"] = {"note": "bytes the lanes ask the memory system for (served mostly by the caches): a demand figure, not a bound",
+                             "bytes_per_frame": b, "GBs_alone": b / (ms_alone * 1e-3) / 1e9, "vs_hbm_peak_alone": b / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "traffic_over_demand": (traffic / b) if traffic else None, "device_walk_counts": c,
+                             "per_ray": {"node_steps": c["node_steps"] / float(rays[0] + rays[3] + rays[4]), "primitive_tests": c["primitive_tests"] / float(rays[0] + rays[3] + rays[4])}}
     # the reference's exhaustive walk priced in bytes and flops, from the oracle's visit counters on the CPU sample
     per_ray = []
     for k in range(3):
@@ -282,6 +311,26 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    # Outside the timed region, the same pipeline once more and longer: the steady-state rate (the K timed steps include
+    # the start and the end of their burst), with a one-wave probe beside it that reads the shader clock the GPU holds
+    # under this very load (the roofline is priced in cycles of that clock).
+    n_steady = 80 if elapsed / args.steps < 3e-3 else 20
+    clock_hz = None
+    steady_s = None
+    if world == 1:
+        try:
+            scene.clock_probe_start(max(1000, int(0.7 * n_steady * elapsed / args.steps * 1e6)))
+        except Exception:
+            pass
+        t1 = time.perf_counter()
+        for _ in range(n_steady):
+            step()
+        fence()
+        steady_s = time.perf_counter() - t1
+        try:
+            clock_hz = scene.clock_probe_read()
+        except Exception:
+            clock_hz = None
     stream = streams[(frame_no[0] - 1) % depth].cuda_stream
     local = locals_[(frame_no[0] - 1) % depth]
     st = scene.stats(stream)
@@ -374,6 +423,9 @@ def main():
             "rays_per_frame": {"primary": int(rays[0]), "shadow": int(rays[1]), "reflection": int(rays[2])},
             "rays_walked_per_frame": {"primary": int(rays[0]), "shadow": int(rays[3]), "reflection": int(rays[4])},
             "self_check": "last frame of each of the %d streams byte-equal to a frame rendered alone" % depth + ("; image assembled from %d ranks byte-equal to the whole image rendered by one GPU" % world if world > 1 else ""),
+            "steady_state": None if steady_s is None else {"frames": n_steady, "value": total_rays * n_steady / steady_s / 1e6, "ms_per_step": steady_s / n_steady * 1e3,
+                                                           "note": "the same pipeline over more frames, outside the timed region: start and end of the burst weigh less"},
+            "shader_clock_hz": clock_hz,        # measured beside the steady-state frames (mirt_clock_probe)
             "frame_alone_ms": frame_alone_ms,   # one frame with nothing else on the GPU: clears + every launch
             "sync_host_ms": sync_host_ms,       # mirt_render: the same plus the copy into the caller's host buffer, host clock
             "kernels": kern,                    # launch durations inside the timed region (launches of frames in flight share the GPU)
@@ -384,7 +436,8 @@ def main():
             # the reference needs minutes to load the 10 M triangle grid: that workload is timed on the C restatement
             base, vis, srays = cpu_baseline_and_visits(flat, scene_text, width, height, row_step, use_reference=args.workload != "grid")
             out["cpu_baseline"] = base
-            out["roofline"] = roofline(scene, flat, args, width, height, trace_mode, rays, vis, srays, kern, kern_alone, elapsed / args.steps)
+            n_simds = 4 * torch.cuda.get_device_properties(dev_index).multi_processor_count
+            out["roofline"] = roofline(scene, flat, args, width, height, trace_mode, rays, vis, srays, kern, kern_alone, elapsed / args.steps, clock_hz, n_simds)
         print(json.dumps(out), flush=True)
     scene.close()
     if world > 1:

@@ -248,6 +248,14 @@ int mirt_scene_query(mirt_scene* scene, uint32_t what, uint64_t* value_out);
 int mirt_set_profiling(mirt_scene* scene, int enabled);
 int mirt_get_launch_times(mirt_scene* scene, void* hip_stream, float* ms_out, int32_t* kinds_out, uint32_t capacity, uint32_t* n_out);
 
+/* Measurement hook: the shader clock the GPU really holds under load (it lowers its clock when busy, so rates priced in
+ * cycles need the clock of the same moment).  mirt_clock_probe_start puts one wave on a stream of the library's own that
+ * reads the shader-cycle counter and the constant 100 MHz counter `microseconds` apart (1..1000000) and returns at once;
+ * frames issued meanwhile run beside it.  mirt_clock_probe_read waits for that wave and gives cycles / second.  Replaces
+ * nothing in the reference (its report knows whole seconds only, main.cpp:131,171). */
+int mirt_clock_probe_start(mirt_scene* scene, uint32_t microseconds);
+int mirt_clock_probe_read(mirt_scene* scene, double* shader_hz);
+
 /* Reassemble an image from `n_ranks` packed tile buffers laid back to back in d_tiles (rank r's buffer at
  * r * per_rank_bytes, rendered with first_tile = r, tile_stride = n_ranks) into d_bgr (width*height*3).
  * The step after the RCCL gather; has no counterpart in the single-threaded reference. */

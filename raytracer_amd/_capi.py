@@ -97,6 +97,8 @@ SYMBOLS = [
     ("mirt_get_stats", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     ("mirt_scene_query", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("mirt_set_profiling", C.c_int, [C.c_void_p, C.c_int]),
+    ("mirt_clock_probe_start", C.c_int, [C.c_void_p, C.c_uint32]),
+    ("mirt_clock_probe_read", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     ("mirt_get_launch_times", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     ("mirt_assemble_tiles", C.c_int, [C.c_int, C.POINTER(RenderParams), C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     ("mirt_trace_rays", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

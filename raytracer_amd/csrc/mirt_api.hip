@@ -149,6 +149,9 @@ inline h3 hnorm(h3 a) { float s = 1.0f / sqrtf(hdot(a, a)); return H3(a.x * s, a
 
 // Working set of the frames issued on one stream.  Frames on different streams own different workspaces, so they may
 // overlap on the GPU (the short, latency-bound deep-bounce launches of one frame run beside the bulk of the next).
+#define DBG_WORDS 40      // 64-bit words of mirt_scene::dbg: 0..31 event counters of diagnostic builds, 32..33 the clock probe
+#define DBG_CLOCK 32
+
 struct FrameCtx {
 	hipStream_t stream = nullptr;
 	Workspace ws;
@@ -298,6 +301,7 @@ struct mirt_scene {
 	uint32_t bvhDepth = 0;
 	bool deepBvh = false;    // hierarchy deeper than the LDS part of the traversal stack
 	hipStream_t stream = nullptr; // used by the synchronous entry points
+	hipStream_t probeStream = nullptr; // mirt_clock_probe_start's own stream (created at its first call)
 	uint32_t nLights = 0;
 	int32_t maxDepth = 0;
 	uint32_t wideDepth = 0;
@@ -1507,7 +1511,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	if (!e && hipGetDeviceProperties(&prop, device) != hipSuccess) e = fail(MIRT_E_DEVICE, "hipGetDeviceProperties failed");
 	if (!e) s->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	if (!e) e = scratch_init(device);
-	if (!e) { e = s->dbg.ensure(32 * 8); if (!e) (void)hipMemset(s->dbg.p, 0, 32 * 8); }
+	if (!e) { e = s->dbg.ensure(DBG_WORDS * 8); if (!e) (void)hipMemset(s->dbg.p, 0, DBG_WORDS * 8); }
 	ds.dbg = (unsigned long long*)s->dbg.p;
 	s->ovfStride = (uint32_t)s->numCUs * GRID_BLOCKS_PER_CU * BLOCK;
 	// the most entries a walk can hold: along any path, every node leaves behind all its children but one
@@ -1554,6 +1558,7 @@ void mirt_scene_destroy(mirt_scene* s) {
 		delete c;
 	}
 	if (s->stream) (void)hipStreamDestroy(s->stream);
+	if (s->probeStream) (void)hipStreamDestroy(s->probeStream);
 	delete s;
 }
 
@@ -1742,7 +1747,7 @@ int mirt_scene_load(const char* path, int device, mirt_scene** out, uint32_t use
 			return e;
 		}
 	}
-	if (ok && (s->dbg.ensure(32 * 8) || hipMemset(s->dbg.p, 0, 32 * 8) != hipSuccess)) { ok = false; why = "device allocation failed"; }
+	if (ok && (s->dbg.ensure(DBG_WORDS * 8) || hipMemset(s->dbg.p, 0, DBG_WORDS * 8) != hipSuccess)) { ok = false; why = "device allocation failed"; }
 	if (!ok) {
 		mirt_scene_destroy(s);
 		return fail(MIRT_E_INVALID, "%s: %s", path, why);
@@ -1906,6 +1911,31 @@ int mirt_scene_query(mirt_scene* s, uint32_t what, uint64_t* v) {
 int mirt_set_frames_in_flight(mirt_scene* s, uint32_t n) {
 	if (!s) return fail(MIRT_E_INVALID, "scene handle is NULL");
 	s->framesHint = n;
+	return MIRT_OK;
+}
+
+int mirt_clock_probe_start(mirt_scene* s, uint32_t microseconds) {
+	if (!s) return fail(MIRT_E_INVALID, "scene handle is NULL");
+	if (microseconds == 0 || microseconds > 1000000u) return fail(MIRT_E_INVALID, "clock probe of %u us: 1..1000000 allowed", microseconds);
+	HIPCHK(hipSetDevice(s->device));
+	if (!s->probeStream) HIPCHK(hipStreamCreateWithFlags(&s->probeStream, hipStreamNonBlocking));
+	unsigned long long* out = (unsigned long long*)s->dbg.p + DBG_CLOCK;
+	HIPCHK(hipMemsetAsync(out, 0, 16, s->probeStream));
+	hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, s->probeStream, out, (unsigned long long)microseconds * 100ull);
+	HIPCHK(hipGetLastError());
+	return MIRT_OK;
+}
+
+int mirt_clock_probe_read(mirt_scene* s, double* shader_hz) {
+	if (!s || !shader_hz) return fail(MIRT_E_INVALID, "NULL argument");
+	*shader_hz = 0.0;
+	if (!s->probeStream) return fail(MIRT_E_INVALID, "no clock probe was started");
+	HIPCHK(hipSetDevice(s->device));
+	HIPCHK(hipStreamSynchronize(s->probeStream));
+	unsigned long long v[2] = {0, 0};
+	HIPCHK(hipMemcpy(v, (unsigned long long*)s->dbg.p + DBG_CLOCK, 16, hipMemcpyDeviceToHost));
+	if (v[1] == 0) return fail(MIRT_E_DEVICE, "the clock probe left no reading");
+	*shader_hz = (double)v[0] / (double)v[1] * 1e8;
 	return MIRT_OK;
 }
 

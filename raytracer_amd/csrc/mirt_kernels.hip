@@ -1703,6 +1703,23 @@ __global__ __launch_bounds__(BLOCK) void k_test_powf(uint64_t n, const float* __
 	for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) out[i] = ref_powf(x[i], y[i]);
 }
 
+// ---- measurement hook: the shader clock the GPU holds while this wave is resident ------------------------------------------------
+// One wave notes the shader-cycle counter and the constant 100 MHz counter, sleeps until `ticks` of the latter have passed
+// (the host bounds them: the loop ends whatever else the GPU does) and notes both again: out = { shader cycles, 100 MHz ticks }.
+__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long* __restrict__ out, unsigned long long ticks) {
+	const unsigned long long r0 = wall_clock64(), c0 = (unsigned long long)clock64();
+	unsigned long long r1 = r0;
+	while (r1 - r0 < ticks) {
+		__builtin_amdgcn_s_sleep(64);
+		r1 = wall_clock64();
+	}
+	const unsigned long long c1 = (unsigned long long)clock64();
+	if (threadIdx.x == 0) {
+		out[0] = c1 - c0;
+		out[1] = r1 - r0;
+	}
+}
+
 // ---- multi-GPU: put gathered per-rank tile buffers back into one image --------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_assemble(uint32_t width, uint32_t height, uint32_t tileW, uint32_t tileH, uint32_t tilesX,
                                                    uint32_t nRanks, const uint8_t* __restrict__ tiles, size_t perRank, uint8_t* __restrict__ bgr) {

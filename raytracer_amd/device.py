@@ -114,6 +114,16 @@ class DeviceScene:
     def set_profiling(self, on=True):
         _check(self.lib, self.lib.mirt_set_profiling(self.h, 1 if on else 0))
 
+    def clock_probe_start(self, microseconds):
+        """One wave that reads the shader-cycle counter `microseconds` apart, on a stream of its own; returns at once."""
+        _check(self.lib, self.lib.mirt_clock_probe_start(self.h, int(microseconds)))
+
+    def clock_probe_read(self):
+        """Shader clock in Hz over the probe's interval (waits for the probe)."""
+        hz = C.c_double()
+        _check(self.lib, self.lib.mirt_clock_probe_read(self.h, C.byref(hz)))
+        return float(hz.value)
+
     def launch_times(self, stream_ptr=0):
         """[(kernel name, ms)] of the most recent frame, in issue order (needs set_profiling(True))."""
         ms = (C.c_float * 96)()

@@ -14,17 +14,21 @@ from raytracer_amd.scene import FlatScene  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="scene7")
 ap.add_argument("--workload", default=None, help="dragon | cornell | spheres | grid: generated scene text instead of --scene")
-ap.add_argument("--width", type=int, default=3840)
-ap.add_argument("--height", type=int, default=2160)
+ap.add_argument("--width", type=int, default=0)
+ap.add_argument("--height", type=int, default=0)
 ap.add_argument("--mode", type=int, default=0)
 ap.add_argument("--reps", type=int, default=5)
 a = ap.parse_args()
 if a.workload:
     from raytracer_amd import workloads  # noqa: E402
-    gen = {"dragon": workloads.dragon, "cornell": workloads.cornell, "spheres": workloads.spheres, "grid": workloads.dragon_grid}
-    flat = FlatScene.from_text(gen[a.workload](a.width, a.height))
+    gen = {"dragon": (workloads.dragon, 3840, 2160), "dragon8k": (workloads.dragon, 7680, 4320), "cornell": (workloads.cornell, 640, 480),
+           "spheres": (workloads.spheres, 1920, 1080), "grid": (workloads.dragon_grid, 3840, 2160)}  # bench.py's sizes
+    fn, w0, h0 = gen[a.workload]
+    a.width, a.height = a.width or w0, a.height or h0
+    flat = FlatScene.from_text(fn(a.width, a.height))
     a.scene = a.workload
 else:
+    a.width, a.height = a.width or 3840, a.height or 2160
     flat = FlatScene.load(os.path.join(ROOT, "tests", "golden", a.scene + ".flat.npz"))
 with DeviceScene(flat, 0) as s:
     out = np.zeros((a.height, a.width, 3), np.uint8)
