@@ -186,6 +186,14 @@ int mirt_scene_load(const char* path, int device, mirt_scene** out, uint32_t use
  * (Renderer.h:9, Renderer.cpp:13).  Synchronous.  stats may be NULL. */
 int mirt_render(mirt_scene* scene, const mirt_render_params* params, uint8_t* bgr_out, mirt_stats* stats);
 
+/* Replaces the pixel loop AND the PNG save behind it (main.cpp:137-169: the loop, then Renderer::createImage,
+ * Renderer.cpp:12-15) in one call: the frame is rendered, the GPU turns it into PNG rows where it lies (filter byte, R,G,B
+ * per pixel, "Up"-filtered), the rows come over in bands and CPU threads deflate each stripe of rows as soon as its band
+ * has arrived, while later bands are still on the bus.  The file decodes to exactly the pixels mirt_render delivers (and
+ * FreeImage would have written); its bytes differ from FreeImage's (deflate settings are free in PNG).  Whole images only
+ * (tile_stride 1, tile_w = tile_h = 0).  Synchronous.  stats may be NULL. */
+int mirt_render_png(mirt_scene* scene, const mirt_render_params* params, const char* path, mirt_stats* stats);
+
 /* Same work, asynchronous, output left in device memory.  d_out receives the selected tiles packed one
  * after another in increasing tile number, each tile tile_w*tile_h pixels row-major inside the tile, 3 bytes
  * B,G,R per pixel, edge tiles padded to full size (mirt_tile_buffer_bytes gives the size).  With

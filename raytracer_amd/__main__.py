@@ -16,7 +16,6 @@ import time
 
 from . import _capi
 from .device import DeviceScene
-from .png import write_png
 from .scene import FlatScene
 
 FEATURE_NAMES = [(1, "DIFFUSE"), (2, "SPECULAR"), (4, "SHADOWS"), (8, "REFLECTIONS")]            # main.cpp:35-49
@@ -24,22 +23,22 @@ DEBUG_NAMES = ["DIFFUSE_INTENSITY", "SPECULAR_INTENSITY", "NORMAL_MAP", "SHADOW_
                "LIGHT_DIRECTION_MAP", "NONE"]                                                     # main.cpp:24-33
 
 
-def render_cached(cache_path, out_path, size=None, features=_capi.F_ALL, debug=_capi.DEBUG_NONE, device=0):
+def render_cached(cache_path, out_path, size=None, features=_capi.F_ALL, debug=_capi.DEBUG_NONE, device=0, want_image=True):
     """Render from a scene cache file.  Returns (image, stats, report lines)."""
     t0 = time.perf_counter()
     scene, user = DeviceScene.load(cache_path, device)
     t_load = time.perf_counter() - t0
     w, h = size or (user[0], user[1])
     with scene as s:
-        img, st = s.render(w, h, features=features, debug=debug)
+        t0 = time.perf_counter()
+        st = s.render_png(out_path, w, h, features=features, debug=debug)   # frame + PNG file in one call
+        t_png = time.perf_counter() - t0
+        img = s.render(w, h, features=features, debug=debug)[0] if want_image else None
         facts = s.query()
-    t0 = time.perf_counter()
-    write_png(out_path, img)
-    t_png = time.perf_counter() - t0
     rays = st["primary_rays"] + st["shadow_rays"] + st["reflection_rays"]
     lines = ["PERFORMANCE REPORT FOR " + os.path.basename(out_path), "Scene cache: %s (%d bytes on the device)" % (cache_path, facts["device_bytes"]),
              "Resolution: %dx%d" % (w, h), "Render Time: %.3f ms on the device" % st["device_ms"],
-             "Scene from cache: %.3f s, PNG: %.3f s" % (t_load, t_png),
+             "Scene from cache: %.3f s, frame + PNG file: %.3f s" % (t_load, t_png),
              "Rays: %d primary, %d shadow, %d reflection (%.1f Mrays/s)" % (st["primary_rays"], st["shadow_rays"], st["reflection_rays"], rays / max(st["device_ms"], 1e-9) / 1e3)]
     return img, st, lines
 
@@ -67,10 +66,12 @@ def cache_matches(cache_path, scene_path):
     return (user[2], user[3]) == text_digest(scene_path)
 
 
-def render_file(scene_path, out_path=None, size=None, features=_capi.F_ALL, debug=_capi.DEBUG_NONE, device=0, report=True, cache=None):
+def render_file(scene_path, out_path=None, size=None, features=_capi.F_ALL, debug=_capi.DEBUG_NONE, device=0, report=True, cache=None, want_image=True):
+    """The whole of createRender (main.cpp:104-173).  The PNG file comes from mirt_render_png (frame, PNG rows on the device,
+    deflate as the rows arrive); want_image also fetches the frame as an array (one more frame) for the caller."""
     if cache and os.path.exists(cache):
         if cache_matches(cache, scene_path):
-            return render_cached(cache, out_path or os.path.splitext(os.path.basename(scene_path))[0] + ".png", size, features, debug, device)
+            return render_cached(cache, out_path or os.path.splitext(os.path.basename(scene_path))[0] + ".png", size, features, debug, device, want_image)
         print("%s was not written from %s as it is now: building the scene again" % (cache, scene_path))
     t0 = time.perf_counter()
     flat = FlatScene.from_file(scene_path)
@@ -83,10 +84,10 @@ def render_file(scene_path, out_path=None, size=None, features=_capi.F_ALL, debu
         t_upload = time.perf_counter() - t0
         if cache:
             s.save(cache, user=(flat.width, flat.height) + text_digest(scene_path))
-        img, st = s.render(flat.width, flat.height, features=features, debug=debug)
-    t0 = time.perf_counter()
-    write_png(out_path, img)
-    t_png = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        st = s.render_png(out_path, flat.width, flat.height, features=features, debug=debug)
+        t_png = time.perf_counter() - t0
+        img = s.render(flat.width, flat.height, features=features, debug=debug)[0] if want_image else None
     lines = []
     if report:
         n_px = flat.width * flat.height
@@ -103,7 +104,7 @@ def render_file(scene_path, out_path=None, size=None, features=_capi.F_ALL, debu
             "Render Time: %.3f ms on the device" % st["device_ms"],
             "Milliseconds Per Pixel: %.3g" % (st["device_ms"] / n_px), "",
             "Time Breakdown",
-            "Scene load + tree build: %.3f s, upload: %.3f s, PNG: %.3f s" % (t_load, t_upload, t_png),
+            "Scene load + tree build: %.3f s, upload: %.3f s, frame + PNG file: %.3f s" % (t_load, t_upload, t_png),
             "Rays: %d primary, %d shadow, %d reflection (%.1f Mrays/s)" % (st["primary_rays"], st["shadow_rays"], st["reflection_rays"], rays / max(st["device_ms"], 1e-9) / 1e3),
             "Total objects: %d" % flat.n_prims, "----- Spheres: %d" % flat.spheres.shape[0], "----- Triangles: %d" % flat.tri_verts.shape[0],
             "Total lights: %d" % flat.lights.shape[0], "----- Directional: %d" % (flat.lights.shape[0] - point), "----- Point: %d" % point,
@@ -124,7 +125,7 @@ def main():
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--cache", help="scene cache file: written after the first load, read instead of the scene text afterwards")
     a = ap.parse_args()
-    _, _, lines = render_file(a.scene, a.out, a.size, a.features, a.debug, a.device, cache=a.cache)
+    _, _, lines = render_file(a.scene, a.out, a.size, a.features, a.debug, a.device, cache=a.cache, want_image=False)
     print("\n".join(lines))
 
 

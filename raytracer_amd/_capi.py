@@ -96,6 +96,7 @@ SYMBOLS = [
     ("mirt_set_frames_in_flight", C.c_int, [C.c_void_p, C.c_uint32]),
     ("mirt_get_stats", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     ("mirt_scene_query", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
+    ("mirt_render_png", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_char_p, C.POINTER(Stats)]),
     ("mirt_set_profiling", C.c_int, [C.c_void_p, C.c_int]),
     ("mirt_clock_probe_start", C.c_int, [C.c_void_p, C.c_uint32]),
     ("mirt_clock_probe_read", C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),

@@ -289,6 +289,25 @@ struct CopyBack {
 	}
 };
 
+// mirt_render_png: PNG rows made on the device behind the frame, brought over in bands, deflated as they arrive.
+struct PngPipe {
+	static const int MAX_BANDS = 64;
+	void* staging = nullptr;      // page-locked: the PNG rows of the whole image
+	size_t stagingBytes = 0;
+	uint32_t* flags = nullptr;    // page-locked: MIRT_PNG_MAX_STRIPES words, 1 = the stripe holds something
+	DevBuf rows, dflags;
+	hipEvent_t evFlags = nullptr, ev[MAX_BANDS];
+	int nEv = 0;
+	~PngPipe() {
+		if (staging) (void)hipHostFree(staging);
+		if (flags) (void)hipHostFree(flags);
+		if (evFlags) (void)hipEventDestroy(evFlags);
+		for (int i = 0; i < nEv; ++i) (void)hipEventDestroy(ev[i]);
+		rows.release();
+		dflags.release();
+	}
+};
+
 struct mirt_scene {
 	int device = 0;
 	int numCUs = 256;
@@ -314,6 +333,7 @@ struct mirt_scene {
 	// copy to pageable memory takes 1.4 ms for the 24.9 MB of a 4K frame; page-locking the caller's buffer in place
 	// (hipHostRegister) is refused on the machines this was developed on.  MIRT_COPY_THREADS=0 goes back to the plain copy.
 	CopyBack* copyBack = nullptr;
+	PngPipe* png = nullptr;
 	int copyThreads = 6;
 	uint32_t framesHint = 0;  // frames the caller says it keeps in flight (mirt_set_frames_in_flight); 0, 1: not said
 	bool singleLaunch = true; // frames run as one launch (k_frame) where that kernel applies; MIRT_SINGLE_LAUNCH=0: one launch per depth
@@ -1548,6 +1568,8 @@ void mirt_scene_destroy(mirt_scene* s) {
 	(void)hipDeviceSynchronize();
 	delete s->copyBack;
 	s->copyBack = nullptr;
+	delete s->png;
+	s->png = nullptr;
 	s->nodes.release(); s->leafs.release(); s->bvh.release(); s->memb.release(); s->tris.release(); s->triX.release(); s->triInfo.release();
 	s->spheres.release(); s->sphInfo.release(); s->materials.release(); s->lights.release(); s->hookOvf.release(); s->dbg.release();
 	for (FrameCtx* c : s->ctxs) {
@@ -2023,6 +2045,74 @@ int mirt_render(mirt_scene* s, const mirt_render_params* p, uint8_t* bgr_out, mi
 			}
 		}
 	}
+	if (stats) return read_stats(s, s->stream, stats);
+	return MIRT_OK;
+}
+
+int mirt_render_png(mirt_scene* s, const mirt_render_params* p, const char* path, mirt_stats* stats) {
+	uint32_t tileW, tileH;
+	int e = check_params(s, p, tileW, tileH);
+	if (e) return e;
+	if (!path) return fail(MIRT_E_INVALID, "path is NULL");
+	if (packed_layout(p)) return fail(MIRT_E_INVALID, "mirt_render_png writes whole images only (tile_stride 1, default tiles)");
+	HIPCHK(hipSetDevice(s->device));
+	const uint32_t w = p->width, h = p->height;
+	const size_t bytes = (size_t)w * h * 3, line = 1 + (size_t)w * 3, rowBytes = line * h;
+	FrameCtx* c = ctx_for(s, s->stream, true);
+	if (!c) return MIRT_E_INVALID;
+	if ((e = c->ws.out.ensure(bytes))) return e;
+	if (!s->png) s->png = new (std::nothrow) PngPipe();
+	PngPipe* pp = s->png;
+	if (!pp) return fail(MIRT_E_NOMEM, "out of host memory");
+	if ((e = pp->rows.ensure(rowBytes)) || (e = pp->dflags.ensure(MIRT_PNG_MAX_STRIPES * 4))) return e;
+	if (rowBytes > pp->stagingBytes) {
+		if (pp->staging) (void)hipHostFree(pp->staging);
+		pp->staging = nullptr;
+		pp->stagingBytes = 0;
+		HIPCHK(hipHostMalloc(&pp->staging, rowBytes, hipHostMallocDefault));
+		pp->stagingBytes = rowBytes;
+	}
+	if (!pp->flags) HIPCHK(hipHostMalloc((void**)&pp->flags, MIRT_PNG_MAX_STRIPES * 4, hipHostMallocDefault));
+	if (!pp->evFlags) HIPCHK(hipEventCreateWithFlags(&pp->evFlags, hipEventDisableTiming));
+	// bands of about 2 MB, each a whole number of 256-byte pieces; a stripe's rows have arrived when the band that holds
+	// their last byte has
+	int want = (int)((rowBytes + (2u << 20) - 1) / (2u << 20));
+	want = want < 1 ? 1 : (want > PngPipe::MAX_BANDS ? PngPipe::MAX_BANDS : want);
+	while (pp->nEv < want) { HIPCHK(hipEventCreateWithFlags(&pp->ev[pp->nEv], hipEventDisableTiming)); ++pp->nEv; }
+	const size_t band = ((rowBytes + want - 1) / want + 255) & ~(size_t)255;
+	const int nBands = (int)((rowBytes + band - 1) / band);
+	const uint32_t nStripes = mirt_png_stripes(w, h), rowsPerStripe = (h + nStripes - 1) / nStripes;
+	// the frame, its PNG rows, the stripes' flags, then the rows band by band: all queued before the host waits for anything
+	if ((e = render_async(s, p, c->ws.out.p, bytes, s->stream, false))) return e;
+	HIPCHK(hipMemsetAsync(pp->dflags.p, 0, MIRT_PNG_MAX_STRIPES * 4, s->stream));
+	{
+		const uint64_t n = (uint64_t)w * h;
+		const uint64_t blocks = (n + BLOCK - 1) / BLOCK;
+		hipLaunchKernelGGL(k_png_rows, dim3((uint32_t)(blocks < 65536u * 16u ? blocks : 65536u * 16u)), dim3(BLOCK), 0, s->stream, (const uint8_t*)c->ws.out.p, w, h, rowsPerStripe,
+		                   (uint8_t*)pp->rows.p, (uint32_t*)pp->dflags.p);
+		HIPCHK(hipGetLastError());
+	}
+	HIPCHK(hipMemcpyAsync(pp->flags, pp->dflags.p, MIRT_PNG_MAX_STRIPES * 4, hipMemcpyDeviceToHost, s->stream));
+	HIPCHK(hipEventRecord(pp->evFlags, s->stream));
+	for (int k = 0; k < nBands; ++k) {
+		const size_t at = (size_t)k * band, len = at + band <= rowBytes ? band : rowBytes - at;
+		HIPCHK(hipMemcpyAsync((uint8_t*)pp->staging + at, (const uint8_t*)pp->rows.p + at, len, hipMemcpyDeviceToHost, s->stream));
+		HIPCHK(hipEventRecord(pp->ev[k], s->stream));
+	}
+	const int device = s->device;
+	e = mirt_png_encode(path, w, h, 0, 2, 3 /* Z_RLE: the rows are filtered */, [&](uint32_t stripe, uint32_t row0, uint32_t row1, std::vector<uint8_t>&, bool* zero) -> const uint8_t* {
+		static thread_local int current = -1;
+		if (current != device) { if (hipSetDevice(device) != hipSuccess) return nullptr; current = device; }
+		if (hipEventSynchronize(pp->evFlags) != hipSuccess) return nullptr;
+		if (stripe < MIRT_PNG_MAX_STRIPES && pp->flags[stripe] == 0u) { *zero = true; return nullptr; }
+		const size_t lastByte = (size_t)row1 * line - 1;
+		if (hipEventSynchronize(pp->ev[lastByte / band]) != hipSuccess) return nullptr;
+		return (const uint8_t*)pp->staging + (size_t)row0 * line;
+	});
+	// (bands of stripes that were not looked at may still be on their way: the staging buffer is this scene's until they are in)
+	const hipError_t se = hipStreamSynchronize(s->stream);
+	if (e) return e;
+	if (se != hipSuccess) return fail(MIRT_E_DEVICE, "hipStreamSynchronize: %s", hipGetErrorString(se));
 	if (stats) return read_stats(s, s->stream, stats);
 	return MIRT_OK;
 }

@@ -1650,6 +1650,36 @@ __global__ __launch_bounds__(BLOCK) void k_note_parts(const uint8_t* __restrict_
 	if (__builtin_amdgcn_ballot_w64(any != 0u) && (threadIdx.x & 63u) == 0u) parts[part] = 1u;
 }
 
+// ---- PNG rows of a finished image --------------------------------------------------------------------------------------------
+// What Renderer::createImage hands to the PNG writer (Renderer.cpp:13-14), made where the image lies: row i of `rows` is
+// the filter-type byte 2 ("Up", PNG specification 6.3) followed by R,G,B of every pixel, each byte minus the same byte of
+// the row above (row 0: minus nothing), modulo 256.  stripeAny[i / rowsPerStripe] = 1 when a stripe of rows holds a
+// filtered byte that is not 0 (the words are cleared before the launch); a stripe without one deflates to a stream that
+// depends on its shape alone.  One thread per pixel.
+__global__ __launch_bounds__(BLOCK) void k_png_rows(const uint8_t* __restrict__ bgr, uint32_t width, uint32_t height, uint32_t rowsPerStripe,
+                                                   uint8_t* __restrict__ rows, uint32_t* __restrict__ stripeAny) {
+	const uint64_t n = (uint64_t)width * height;
+	const size_t line = 1 + (size_t)width * 3;
+	for (uint64_t k = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; k < n; k += (uint64_t)gridDim.x * BLOCK) {
+		const uint32_t i = (uint32_t)(k / width), j = (uint32_t)(k - (uint64_t)i * width);
+		const uint8_t* src = bgr + 3 * k;
+		uint8_t b = src[0], g = src[1], r = src[2]; // main.cpp:154-156 stores B,G,R
+		if (i > 0) {
+			const uint8_t* up = src - (size_t)width * 3;
+			b = (uint8_t)(b - up[0]);
+			g = (uint8_t)(g - up[1]);
+			r = (uint8_t)(r - up[2]);
+		}
+		uint8_t* dst = rows + (size_t)i * line;
+		if (j == 0) dst[0] = 2;
+		dst += 1 + (size_t)j * 3;
+		dst[0] = r;
+		dst[1] = g;
+		dst[2] = b;
+		if (r | g | b) stripeAny[i / rowsPerStripe] = 1u;
+	}
+}
+
 // ---- narrow seam: closest hit for a list of rays ----------------------------------------------------------------------
 template <int MODE, bool OVF>
 __global__ __launch_bounds__(BLOCK) void k_trace_list(DScene S, uint32_t* ovf, uint32_t ovfStride, uint64_t n, const float* __restrict__ o3, const float* __restrict__ d3,

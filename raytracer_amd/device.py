@@ -80,6 +80,13 @@ class DeviceScene:
         _check(self.lib, self.lib.mirt_render(self.h, C.byref(p), out.ctypes.data, C.byref(st)))
         return out, st.as_dict()
 
+    def render_png(self, path, width=None, height=None, features=F_ALL, debug=DEBUG_NONE, trace_mode=TRACE_EXACT):
+        """Frame and PNG file in one call (mirt_render_png): the PNG rows are made on the device and deflated as they arrive."""
+        p = make_params(width or self.flat.width, height or self.flat.height, features, debug, trace_mode)
+        st = Stats()
+        _check(self.lib, self.lib.mirt_render_png(self.h, C.byref(p), str(path).encode(), C.byref(st)))
+        return st.as_dict()
+
     # ---- asynchronous, device buffer out (torch tensor or raw pointer) ------------------------------------------------
     def tile_buffer_bytes(self, params):
         return int(self.lib.mirt_tile_buffer_bytes(C.byref(params)))
