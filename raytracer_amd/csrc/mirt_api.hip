@@ -161,6 +161,11 @@ struct FrameCtx {
 	uint32_t lastFeatures = 0;
 	bool lastValid = false;
 	bool lastSingle = false; // the last frame ran as one launch (k_frame): its counters are laid out differently
+	// The counters buffer holds TWO blocks of CTR_COUNT words.  A frame uses block ctrPhase, which is all zeros when the
+	// frame starts: the frame before it on this stream cleared it (k_frame does that itself, the per-depth path with a
+	// memset at its own start), and both were cleared when the buffer was allocated.
+	uint32_t ctrPhase = 0;
+	const uint32_t* lastCtr = nullptr; // the block of the last frame
 	std::vector<hipEvent_t> launchEv;
 	std::vector<int32_t> launchKind;
 	uint32_t nLaunches = 0;
@@ -911,7 +916,7 @@ FrameLayout frame_layout(const mirt_scene* s, size_t n, bool single) {
 	const size_t depths = (size_t)s->maxDepth + 1, nl = s->nLights;
 	FrameLayout L;
 	memset(&L, 0, sizeof L);
-	L.bytes[WS_COUNTERS] = CTR_COUNT * 4;
+	L.bytes[WS_COUNTERS] = 2 * CTR_COUNT * 4; // two blocks (FrameCtx::ctrPhase)
 	L.bytes[WS_OVF] = s->deepBvh ? (size_t)s->ovfLevels * s->ovfStride * 4 : 0;
 	if (single) {
 		// k_frame: one hit record per slot, one light sum (with the material index) per slot and depth
@@ -943,7 +948,7 @@ int frame_checks(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 // Puts one frame on the stream: clears, every launch of the frame.  mem[] are the arrays of frame_layout(); c may be NULL
 // (no per-launch profiling then).  Allocates nothing.
 int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const TileGeom& g, uint32_t tileW, uint32_t tileH, bool packed, bool single,
-                  void* const mem[WS_N], void* d_out, size_t need, hipStream_t st, int othersInFlight = 0) {
+                  void* const mem[WS_N], void* d_out, size_t need, hipStream_t st, int othersInFlight = 0, bool ctrReady = false) {
 	const size_t n = (size_t)g.nSlots;
 	DFrame F;
 	F.ovf = (uint32_t*)mem[WS_OVF];
@@ -953,7 +958,6 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 	F.litL = (float4*)mem[WS_LITL]; F.litS = (float4*)mem[WS_LITS];
 	F.pathDepth = (uint8_t*)mem[WS_PATHDEPTH];
 	F.active = (uint32_t*)mem[WS_ACTIVE];
-	F.counters = (uint32_t*)mem[WS_COUNTERS];
 	F.nSlots = (uint32_t)g.nSlots;
 	F.width = p->width; F.height = p->height;
 	F.tileW = tileW; F.tileH = tileH; F.tilesX = g.tilesX; F.nTilesLocal = g.nLocal;
@@ -966,6 +970,7 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 	F.divTilesX = make_div(g.tilesX);
 	// bytes of tiles that are not rendered must stay untouched in the full-image layout, so only clear when all are
 	F.preCleared = (packed || p->tile_stride == 1) ? 1u : 0u;
+	F.wideClear = (((uintptr_t)d_out & 3u) == 0 && (packed || (p->width & 3u) == 0)) ? 1u : 0u;
 	// The order of k_frame's batches.  In image order the blocks that see the scene come in long runs (the rows the object
 	// covers) between runs that see nothing, and all waves are in the same kind of run at the same time.  Stepping through
 	// the blocks with a stride of about 1/128 of the frame (made coprime to the number of blocks, so every block comes
@@ -983,10 +988,36 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 			F.batchMul = (uint32_t)m;
 		}
 	}
-	HIPCHK(hipMemsetAsync(F.counters, 0, CTR_COUNT * 4, st));
-	if (F.preCleared) {
-		HIPCHK(hipMemsetAsync(d_out, 0, need, st));
-		if (!single) HIPCHK(hipMemsetAsync(F.pathDepth, 0, n, st));
+	// Clears: of the counters, of the output (the background is black, main.cpp:124,180) and of the path depths.
+	// k_frame can do without the two queued in front of it (MIRT_CLEAR_IN_KERNEL=1): every pixel slot then writes its own
+	// pixel, black ones included (blocks of 8x8 that see nothing as 48 words), and the counter block it uses was cleared by
+	// the stream's previous frame (ctrReady; without a stream context -- the entry point that allocates nothing -- it is
+	// cleared here).  With eight frames in flight a queued clear lasts 0.28-0.44 ms on average (5 us alone: it has to find
+	// room beside the frames of other streams) and the two together are 13-16 % of the summed launch durations -- but that
+	// time is not lost: measured on the Stanford dragon at 3840x2160, frames without queued clears run 14.00 against 14.10
+	// Grays/s over 80 frames and 13.0 against 13.7 over 20 (a burst of frames that all start at the same moment also end
+	// together; the clears in front of them spread their starts).  So the queued clears stay the default.
+	const char* cikEnv = getenv("MIRT_CLEAR_IN_KERNEL"); // (read per frame: tests switch it)
+	const bool clearInKernel = cikEnv && *cikEnv == '1';
+	uint32_t* const ctrBase = (uint32_t*)mem[WS_COUNTERS];
+	const uint32_t phase = c ? c->ctrPhase : 0u;
+	F.counters = ctrBase + (size_t)phase * CTR_COUNT;
+	F.countersNext = nullptr;
+	if (single && clearInKernel) {
+		F.preCleared = 0u;
+		if (ctrReady) F.countersNext = ctrBase + (size_t)(1u - phase) * CTR_COUNT;
+		else HIPCHK(hipMemsetAsync(F.counters, 0, CTR_COUNT * 4, st));
+	}
+	else {
+		HIPCHK(hipMemsetAsync(ctrBase, 0, 2 * CTR_COUNT * 4, st)); // this frame's block and the next frame's
+		if (F.preCleared) {
+			HIPCHK(hipMemsetAsync(d_out, 0, need, st));
+			if (!single) HIPCHK(hipMemsetAsync(F.pathDepth, 0, n, st));
+		}
+	}
+	if (c) {
+		c->lastCtr = F.counters;
+		c->ctrPhase = 1u - phase;
 	}
 	if (single) {
 		// Waves of the launch per SIMD.  A frame alone wants every place on the GPU (7): its time is the chain of rounds
@@ -1070,8 +1101,13 @@ int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 	DevBuf* const bufs[WS_N] = {&w.hitO, &w.hitD, &w.hitN, &w.shRes, &w.litL, &w.litS, &w.pathDepth, &w.active, &w.counters, &w.ovf};
 	void* mem[WS_N];
 	for (int k = 0; k < WS_N; ++k) {
+		const void* before = bufs[k]->p;
 		if (L.bytes[k] && (e = bufs[k]->ensure(L.bytes[k]))) return e;
 		mem[k] = bufs[k]->p;
+		if (k == WS_COUNTERS && bufs[k]->p != before) { // a new counters buffer: both blocks start as zeros
+			HIPCHK(hipMemsetAsync(bufs[k]->p, 0, 2 * CTR_COUNT * 4, st));
+			c->ctrPhase = 0;
+		}
 	}
 	// frames of this scene still on the GPU on other streams (their closing events have not happened yet)
 	int others = 0;
@@ -1080,7 +1116,7 @@ int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 	(void)hipGetLastError(); // (hipErrorNotReady is an answer, not a failure)
 	if (s->framesHint > 1 && others < (int)s->framesHint - 1) others = (int)s->framesHint - 1;
 	HIPCHK(hipEventRecord(c->ev0, st));
-	if ((e = enqueue_frame(s, c, p, g, tileW, tileH, packed, single, mem, d_out, need, st, others))) return e;
+	if ((e = enqueue_frame(s, c, p, g, tileW, tileH, packed, single, mem, d_out, need, st, others, true))) return e;
 	HIPCHK(hipEventRecord(c->ev1, st));
 	c->lastSingle = single;
 	c->lastPrimary = g.livePixels;
@@ -1097,7 +1133,7 @@ int read_stats(mirt_scene* s, hipStream_t st, mirt_stats* out) {
 	out->primary_rays = c->lastPrimary;
 	if (!c->lastValid) return MIRT_OK;
 	uint32_t cnt[CTR_COUNT];
-	HIPCHK(hipMemcpy(cnt, c->ws.counters.p, sizeof cnt, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(cnt, c->lastCtr, sizeof cnt, hipMemcpyDeviceToHost));
 	uint64_t hits = 0, refl = 0;
 	if (c->lastSingle) {
 		hits = cnt[CTR_F_HITS_TOTAL];
@@ -2015,15 +2051,15 @@ int mirt_render(mirt_scene* s, const mirt_render_params* p, uint8_t* bgr_out, mi
 	while ((bytes >> shift) >= CTR_NPARTS) ++shift;
 	// (only a frame that really ran has a counter block to note in: with maxdepth < 0 the image is a plain clear and no
 	// workspace exists)
-	const bool noted = staged && sparse && c->lastValid && c->ws.counters.p != nullptr;
+	const bool noted = staged && sparse && c->lastValid && c->lastCtr != nullptr;
 	if (noted) {
 		const uint32_t nParts = (uint32_t)((bytes + ((size_t)1 << shift) - 1) >> shift), blocksPerPart = 64;
-		hipLaunchKernelGGL(k_note_parts, dim3(nParts * blocksPerPart), dim3(BLOCK), 0, s->stream, (const uint8_t*)c->ws.out.p, bytes, shift, blocksPerPart, (uint32_t*)c->ws.counters.p + CTR_PARTS);
+		hipLaunchKernelGGL(k_note_parts, dim3(nParts * blocksPerPart), dim3(BLOCK), 0, s->stream, (const uint8_t*)c->ws.out.p, bytes, shift, blocksPerPart, const_cast<uint32_t*>(c->lastCtr) + CTR_PARTS);
 	}
 	if (whole) {
 		if (staged) {
 			if (!s->copyBack) s->copyBack = new (std::nothrow) CopyBack(s->device, s->copyThreads);
-			if (s->copyBack && s->copyBack->run(c->ws.out.p, bgr_out, bytes, s->stream, noted ? (const uint32_t*)c->ws.counters.p + CTR_PARTS : nullptr, shift)) {
+			if (s->copyBack && s->copyBack->run(c->ws.out.p, bgr_out, bytes, s->stream, noted ? c->lastCtr + CTR_PARTS : nullptr, shift)) {
 				if (stats) return read_stats(s, s->stream, stats);
 				return MIRT_OK;
 			}

@@ -103,6 +103,7 @@ struct DFrame {
 	float4* litL;      // [depth][slot] light sum of the hit at that depth
 	float4* litS;      // [depth][slot] mat.specular of that hit (weight of the next bounce)
 	uint32_t* counters; // see CTR_* below
+	uint32_t* countersNext; // k_frame: the counter block of the stream's next frame, cleared by this one (or NULL)
 	// Traversal-stack overflow area (entries beyond the LDS part), [level][thread of the launch].  It belongs to the
 	// frame's workspace, one per stream: launches of frames on different streams run at the same time and every one of
 	// them indexes the area by its own block and thread numbers.
@@ -114,7 +115,8 @@ struct DFrame {
 	uint32_t features, debug;
 	uint32_t packedTiles; // output layout: 0 = full image, 1 = packed tile buffer
 	uint32_t refillMin;   // k_trace<REFILL>: parked lanes that trigger a refill
-	uint32_t preCleared;  // the output buffer and pathDepth were zeroed before the frame: missed primary rays store nothing
+	uint32_t preCleared;  // the output buffer and pathDepth were zeroed before the frame: missed primary rays store nothing (per-depth launches)
+	uint32_t wideClear;   // k_frame: every row of an 8x8 pixel block starts on a 4-byte boundary of the output (black blocks are written as words)
 	uint32_t batchMul;    // k_frame hands out 8x8 pixel block (b * batchMul) mod nBatches as its b-th batch (0: block b)
 	FastDiv divArea, divSbx, divTilesX; // tile area, 8x8 blocks per tile row, tiles per image row
 };

@@ -1352,6 +1352,11 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 	const uint32_t nWaves = gridDim.x * (FRAME_BLOCK / WAVE);
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (FRAME_BLOCK / WAVE) + (threadIdx.x >> 6));
 	const uint32_t nBatches = (F.nSlots + 63u) >> 6;
+	// The counter block of the NEXT frame on this stream is cleared here, by one wave (nothing else in this launch touches
+	// it, and the next frame starts when this launch has ended): no clear has to be queued in front of a frame.
+	if (wave == 0u && F.countersNext) {
+		for (uint32_t i = (uint32_t)lane; i < CTR_COUNT; i += 64u) F.countersNext[i] = 0u;
+	}
 	// (The number of the next batch is fetched only when the wave is ready for it: fetched ahead, every wave holds back one
 	// batch while it works on the hits of another, and the frame ends a whole batch's chain of rounds later.)
 	uint32_t pbatch = wave;       // the batch of slots to do next; >= nBatches: to be fetched, or none left
@@ -1521,13 +1526,30 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 		// ---- what the answers mean -------------------------------------------------------------------------------------
 		if (!inBatch) {
 			const bool red = hit && F.debug == D_PRIMARY_MAP;   // PRIMARY_INTERSECTION_MAP paints hits pure red (main.cpp:183-185)
-			if (red || (walk && !hit && !F.preCleared)) {       // the background is black (main.cpp:124,180)
+			// The background is black (main.cpp:124,180).  Unless the buffer was cleared beforehand, every slot of the batch that
+			// did not hit writes its own black pixel -- the padding pixels of an edge tile too where they have a place (packed
+			// tiles), so that no byte of the output depends on what the buffer held before.
+			// A batch is an 8x8 block of pixels, eight pieces of 24 bytes.  When none of its 64 camera rays hit anything -- four
+			// batches in five of the Stanford dragon's frame -- 48 lanes write one aligned word each instead of 64 lanes three
+			// bytes each (F.wideClear: rows of the output start on word boundaries).
+			const bool allMiss = F.wideClear && !F.preCleared && walked == ~0ull && __builtin_amdgcn_ballot_w64(hit) == 0ull;
+			if (allMiss) {
+				if (lane < 48) {
+					uint32_t px, py, inTile;
+					const uint32_t first = tag - (uint32_t)lane + 8u * ((uint32_t)lane / 6u); // first slot of the lane's row of the block
+					slot_to_pixel(F, first, px, py, inTile);
+					*(uint32_t*)(out + out_offset(F, first, px, py, inTile) + 4u * ((uint32_t)lane % 6u)) = 0u;
+				}
+			}
+			else if (red || (!hit && !F.preCleared && tag < F.nSlots)) {
 				uint32_t px, py, inTile;
-				slot_to_pixel(F, tag, px, py, inTile);
-				const size_t k = out_offset(F, tag, px, py, inTile);
-				out[k] = 0;
-				out[k + 1] = 0;
-				out[k + 2] = hit ? 255 : 0;
+				const bool live = slot_to_pixel(F, tag, px, py, inTile);
+				if (live || F.packedTiles) {
+					const size_t k = out_offset(F, tag, px, py, inTile);
+					out[k] = 0;
+					out[k + 1] = 0;
+					out[k + 2] = hit ? 255 : 0;
+				}
 			}
 			const bool newHit = hit && !red;
 			if (newHit) {
