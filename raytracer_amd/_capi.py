@@ -118,6 +118,35 @@ SYMBOLS = [
     ("mirt_write_png", C.c_int, [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
 ]
 
+# include/mirt_node.h (libmirt_node.so: libmirt.so + RCCL)
+NODE_SYMBOLS = [
+    ("mirt_node_create", C.c_int, [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("mirt_node_destroy", None, [C.c_void_p]),
+    ("mirt_node_render_device", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("mirt_node_sync", C.c_int, [C.c_void_p, C.c_uint32]),
+    ("mirt_node_render", C.c_int, [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]),
+    ("mirt_node_uses_rccl", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+]
+NODE_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmirt_node.so")
+_node_lib = None
+
+
+def load_node_library():
+    """dlopen libmirt_node.so (it brings libmirt.so and librccl.so with it) and bind include/mirt_node.h."""
+    global _node_lib
+    if _node_lib is None:
+        if not os.path.exists(NODE_LIB_PATH):
+            raise OSError("%s not built (make -C raytracer_amd/csrc)" % NODE_LIB_PATH)
+        load_library()  # the same libmirt.so the node library resolves its symbols against
+        lib = C.CDLL(NODE_LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, res, args in NODE_SYMBOLS:
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _node_lib = lib
+    return _node_lib
+
+
 _lib = None
 
 

@@ -14,9 +14,13 @@ def test_library_exports_every_declared_symbol():
     header = "".join(open(os.path.join(ROOT, "include", h)).read() for h in sorted(os.listdir(os.path.join(ROOT, "include"))) if h.endswith(".h"))
     declared = set(re.findall(r"\b(mirt_[a-z_]+)\s*\(", header))
     bound = {name for name, _, _ in _capi.SYMBOLS}
-    assert declared == bound, (declared ^ bound)
-    for name in declared:
+    node = {name for name, _, _ in _capi.NODE_SYMBOLS}   # include/mirt_node.h lives in libmirt_node.so (libmirt.so + RCCL)
+    assert declared == bound | node, (declared ^ (bound | node))
+    for name in bound:
         assert getattr(lib, name) is not None
+    nlib = _capi.load_node_library()
+    for name in node:
+        assert getattr(nlib, name) is not None
 
 
 def test_struct_sizes_match_header_layout():
