@@ -909,19 +909,36 @@ struct FrameLayout {
 // SIMD), not scenes big enough for lane refilling to pay (k_trace<REFILL> has no counterpart there), not frames whose slot
 // numbers do not fit beside the depth in one word.
 bool single_launch(const mirt_scene* s, const mirt_render_params* p, const TileGeom& g) {
-	return s->singleLaunch && effective_mode(s, p->trace_mode) != MODE_REFWALK && s->refillMin >= 64u && g.nSlots < (1ull << FRAME_SLOT_BITS) && s->maxDepth <= 31;
+	return s->singleLaunch && effective_mode(s, p->trace_mode) != MODE_REFWALK && s->refillMin >= 64u && s->maxDepth <= 31;
 }
 
-FrameLayout frame_layout(const mirt_scene* s, size_t n, bool single) {
+// hit records of a k_frame launch: FRAME_RECORDS for every wave of the largest grid the library launches
+size_t frame_records(const mirt_scene* s) {
+	return (size_t)s->numCUs * GRID_BLOCKS_PER_CU * (BLOCK / FRAME_BLOCK) * (FRAME_BLOCK / WAVE) * FRAME_RECORDS;
+}
+
+// Does a single-launch frame keep its per-path data in hit records (k_frame<RECORDS>) instead of in arrays as long as the
+// image?  Where memory counts more than the last 3 % of speed: the entry point that allocates nothing (its scratch array then
+// takes frames of any size), callers who ask for it (MIRT_FRAME_RECORDS=1), and frames whose slot numbers do not fit beside
+// the depth in one word (2^27 slots and more).
+bool frame_uses_records(const TileGeom& g, bool noalloc) {
+	const char* e = getenv("MIRT_FRAME_RECORDS"); // (read per frame: tests switch it)
+	if (e && *e) return *e != '0';
+	return noalloc || g.nSlots >= (1ull << FRAME_SLOT_BITS);
+}
+
+FrameLayout frame_layout(const mirt_scene* s, size_t n, bool single, bool records) {
 	const size_t depths = (size_t)s->maxDepth + 1, nl = s->nLights;
 	FrameLayout L;
 	memset(&L, 0, sizeof L);
 	L.bytes[WS_COUNTERS] = 2 * CTR_COUNT * 4; // two blocks (FrameCtx::ctrPhase)
 	L.bytes[WS_OVF] = s->deepBvh ? (size_t)s->ovfLevels * s->ovfStride * 4 : 0;
 	if (single) {
-		// k_frame: one hit record per slot, one light sum (with the material index) per slot and depth
-		L.bytes[WS_HITO] = L.bytes[WS_HITD] = L.bytes[WS_HITN] = n * 16;
-		L.bytes[WS_LITL] = depths * n * 16;
+		// k_frame: one 48-byte hit record and one light sum (with the material index) per depth, for every pixel slot -- or,
+		// with records, for each of the FRAME_RECORDS records of every wave of the largest launch, whatever the image's size
+		const size_t nRec = records ? frame_records(s) : n;
+		L.bytes[WS_HITO] = L.bytes[WS_HITD] = L.bytes[WS_HITN] = nRec * 16;
+		L.bytes[WS_LITL] = depths * nRec * 16;
 		return L;
 	}
 	L.bytes[WS_HITO] = L.bytes[WS_HITD] = L.bytes[WS_HITN] = 2 * n * 16;
@@ -947,7 +964,7 @@ int frame_checks(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 
 // Puts one frame on the stream: clears, every launch of the frame.  mem[] are the arrays of frame_layout(); c may be NULL
 // (no per-launch profiling then).  Allocates nothing.
-int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const TileGeom& g, uint32_t tileW, uint32_t tileH, bool packed, bool single,
+int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const TileGeom& g, uint32_t tileW, uint32_t tileH, bool packed, bool single, bool records,
                   void* const mem[WS_N], void* d_out, size_t need, hipStream_t st, int othersInFlight = 0, bool ctrReady = false) {
 	const size_t n = (size_t)g.nSlots;
 	DFrame F;
@@ -958,6 +975,7 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 	F.litL = (float4*)mem[WS_LITL]; F.litS = (float4*)mem[WS_LITS];
 	F.pathDepth = (uint8_t*)mem[WS_PATHDEPTH];
 	F.active = (uint32_t*)mem[WS_ACTIVE];
+	F.nRec = records ? (uint32_t)frame_records(s) : (uint32_t)g.nSlots;
 	F.nSlots = (uint32_t)g.nSlots;
 	F.width = p->width; F.height = p->height;
 	F.tileW = tileW; F.tileH = tileH; F.tilesX = g.tilesX; F.nTilesLocal = g.nLocal;
@@ -1038,9 +1056,14 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 		const int grid = s->numCUs * (gw < GRID_BLOCKS_PER_CU ? gw : GRID_BLOCKS_PER_CU) * (BLOCK / FRAME_BLOCK); // every block resident at once
 		if (c) c->nLaunches = 0;
 		mark(s, c, st, -1);
+#define MIRT_LAUNCH_FRAME(MODE, OVF, SHARE)                                                                                                                  \
+	do {                                                                                                                                                \
+		if (records) hipLaunchKernelGGL((k_frame<MODE, OVF, SHARE, true>), dim3(grid), dim3(FRAME_BLOCK), 0, st, s->ds, F, (uint8_t*)d_out);           \
+		else hipLaunchKernelGGL((k_frame<MODE, OVF, SHARE, false>), dim3(grid), dim3(FRAME_BLOCK), 0, st, s->ds, F, (uint8_t*)d_out);                   \
+	} while (0)
 		if (effective_mode(s, p->trace_mode) == MODE_FAST) {
-			if (s->deepBvh) hipLaunchKernelGGL((k_frame<MODE_FAST, true, false>), dim3(grid), dim3(FRAME_BLOCK), 0, st, s->ds, F, (uint8_t*)d_out);
-			else hipLaunchKernelGGL((k_frame<MODE_FAST, false, false>), dim3(grid), dim3(FRAME_BLOCK), 0, st, s->ds, F, (uint8_t*)d_out);
+			if (s->deepBvh) MIRT_LAUNCH_FRAME(MODE_FAST, true, false);
+			else MIRT_LAUNCH_FRAME(MODE_FAST, false, false);
 		}
 		else {
 			// Lanes of a wave help each other through long walks (walk_wave_share) where walks are long enough for that to pay:
@@ -1050,14 +1073,15 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 			const int shareEnv = shareStr && *shareStr ? atoi(shareStr) : -1;
 			const bool share = FRAME_BLOCK == WAVE && (shareEnv >= 0 ? shareEnv != 0 : s->bvh.bytes / 64 >= 4096);
 			if (s->deepBvh) {
-				if (share) hipLaunchKernelGGL((k_frame<MODE_EXACT, true, true>), dim3(grid), dim3(FRAME_BLOCK), 0, st, s->ds, F, (uint8_t*)d_out);
-				else hipLaunchKernelGGL((k_frame<MODE_EXACT, true, false>), dim3(grid), dim3(FRAME_BLOCK), 0, st, s->ds, F, (uint8_t*)d_out);
+				if (share) MIRT_LAUNCH_FRAME(MODE_EXACT, true, true);
+				else MIRT_LAUNCH_FRAME(MODE_EXACT, true, false);
 			}
 			else {
-				if (share) hipLaunchKernelGGL((k_frame<MODE_EXACT, false, true>), dim3(grid), dim3(FRAME_BLOCK), 0, st, s->ds, F, (uint8_t*)d_out);
-				else hipLaunchKernelGGL((k_frame<MODE_EXACT, false, false>), dim3(grid), dim3(FRAME_BLOCK), 0, st, s->ds, F, (uint8_t*)d_out);
+				if (share) MIRT_LAUNCH_FRAME(MODE_EXACT, false, true);
+				else MIRT_LAUNCH_FRAME(MODE_EXACT, false, false);
 			}
 		}
+#undef MIRT_LAUNCH_FRAME
 		mark(s, c, st, MIRT_K_FRAME);
 		HIPCHK(hipGetLastError());
 		return MIRT_OK;
@@ -1097,7 +1121,8 @@ int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 	}
 	Workspace& w = c->ws;
 	const bool single = single_launch(s, p, g);
-	const FrameLayout L = frame_layout(s, (size_t)g.nSlots, single);
+	const bool records = single && frame_uses_records(g, false);
+	const FrameLayout L = frame_layout(s, (size_t)g.nSlots, single, records);
 	DevBuf* const bufs[WS_N] = {&w.hitO, &w.hitD, &w.hitN, &w.shRes, &w.litL, &w.litS, &w.pathDepth, &w.active, &w.counters, &w.ovf};
 	void* mem[WS_N];
 	for (int k = 0; k < WS_N; ++k) {
@@ -1116,7 +1141,7 @@ int render_async(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 	(void)hipGetLastError(); // (hipErrorNotReady is an answer, not a failure)
 	if (s->framesHint > 1 && others < (int)s->framesHint - 1) others = (int)s->framesHint - 1;
 	HIPCHK(hipEventRecord(c->ev0, st));
-	if ((e = enqueue_frame(s, c, p, g, tileW, tileH, packed, single, mem, d_out, need, st, others, true))) return e;
+	if ((e = enqueue_frame(s, c, p, g, tileW, tileH, packed, single, records, mem, d_out, need, st, others, true))) return e;
 	HIPCHK(hipEventRecord(c->ev1, st));
 	c->lastSingle = single;
 	c->lastPrimary = g.livePixels;
@@ -1575,7 +1600,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	s->diag[6] = stackNeed;
 	// Every kernel keeps at least this many entries in LDS (each variant its own number), so an area sized for the smaller
 	// number serves all of them, and a hierarchy that fits the smaller number needs no overflow variant anywhere.
-	const uint32_t ldsEntries = STACK_LDS_REFILL < STACK_LDS ? STACK_LDS_REFILL : STACK_LDS;
+	const uint32_t ldsEntries = std::min(std::min((uint32_t)STACK_LDS_REFILL, (uint32_t)STACK_LDS), (uint32_t)STACK_LDS_FRAME);
 	s->deepBvh = stackNeed > ldsEntries;
 	s->ovfLevels = s->deepBvh ? stackNeed - ldsEntries : 0u;
 	if (!e && s->deepBvh) e = s->hookOvf.ensure((size_t)s->ovfLevels * s->ovfStride * 4);
@@ -1816,7 +1841,7 @@ int mirt_scene_load(const char* path, int device, mirt_scene** out, uint32_t use
 	// How much of the traversal stack lies beyond LDS depends on THIS build's STACK_LDS, not on the build that wrote the
 	// file: derived again from the stack need of the hierarchy (diag[6]), exactly as mirt_scene_create does.
 	{
-		const uint32_t ldsEntries = STACK_LDS_REFILL < STACK_LDS ? STACK_LDS_REFILL : STACK_LDS;
+		const uint32_t ldsEntries = std::min(std::min((uint32_t)STACK_LDS_REFILL, (uint32_t)STACK_LDS), (uint32_t)STACK_LDS_FRAME);
 		const uint32_t stackNeed = s->diag[6];
 		if (stackNeed == 0 || stackNeed > 4096) { mirt_scene_destroy(s); return fail(MIRT_E_INVALID, "%s: inconsistent header (traversal stack need %u)", path, stackNeed); }
 		s->deepBvh = stackNeed > ldsEntries;
@@ -1885,7 +1910,8 @@ int mirt_render_device_noalloc(mirt_scene* s, const mirt_render_params* p, void*
 	}
 	// the arrays of a frame, carved out of this device's scratch array one after the other, each 256-byte aligned
 	const bool single = single_launch(s, p, g);
-	const FrameLayout L = frame_layout(s, (size_t)g.nSlots, single);
+	const bool records = single && frame_uses_records(g, true);
+	const FrameLayout L = frame_layout(s, (size_t)g.nSlots, single, records);
 	unsigned char* const base = g_scratchPtr[s->device];
 	void* mem[WS_N];
 	size_t at = 0;
@@ -1897,7 +1923,7 @@ int mirt_render_device_noalloc(mirt_scene* s, const mirt_render_params* p, void*
 		return fail(MIRT_E_INVALID, "mirt_render_device_noalloc: this frame needs %zu bytes of working memory (%llu pixel slots, %u lights, maxdepth %d), the fixed scratch array holds %zu; use mirt_render_device",
 		            at, (unsigned long long)g.nSlots, s->nLights, s->maxDepth, (size_t)MIRT_NOALLOC_SCRATCH_BYTES);
 	// counters, path depths and the output are cleared inside enqueue_frame; every other array is written before it is read
-	return enqueue_frame(s, nullptr, p, g, tileW, tileH, packed, single, mem, d_out, need, st);
+	return enqueue_frame(s, nullptr, p, g, tileW, tileH, packed, single, records, mem, d_out, need, st);
 }
 
 int mirt_scene_query(mirt_scene* s, uint32_t what, uint64_t* v) {

@@ -92,7 +92,8 @@ struct FastDiv {
 	uint32_t magic, shift, d, pad;
 };
 
-// One frame's working set.  Every array is indexed by pixel slot: a pixel has exactly one path.
+// One frame's working set.  Every array is indexed by pixel slot (a pixel has exactly one path); k_frame<RECORDS> indexes
+// hitO/hitD/hitN/litL by hit record instead (FRAME_RECORDS per wave of the launch, see k_frame).
 struct DFrame {
 	float4* hitO;      // hit records, two sets of nSlots (depth parity): { ray o.xyz, 0 }
 	float4* hitD;      //            { ray d.xyz, dist }
@@ -102,6 +103,7 @@ struct DFrame {
 	uint8_t* pathDepth; // [slot] number of hits the pixel's path has had so far (0 = primary ray missed)
 	float4* litL;      // [depth][slot] light sum of the hit at that depth
 	float4* litS;      // [depth][slot] mat.specular of that hit (weight of the next bounce)
+	uint32_t nRec;     // k_frame: stride of litL's depth index = entries of hitO/hitD/hitN (pixel slots, or records of the launch)
 	uint32_t* counters; // see CTR_* below
 	uint32_t* countersNext; // k_frame: the counter block of the stream's next frame, cleared by this one (or NULL)
 	// Traversal-stack overflow area (entries beyond the LDS part), [level][thread of the launch].  It belongs to the
@@ -137,4 +139,4 @@ struct DFrame {
 #define CTR_PARTS 192           // 32 words: 1 = that part of the output holds something else than zeros
 #define CTR_NPARTS 32
 #define CTR_COUNT 256
-#define FRAME_SLOT_BITS 27    // k_frame packs slot and depth into one word: fewer than 2^27 slots, depth <= 31
+#define FRAME_SLOT_BITS 27    // k_frame packs slot (or a wave's record number) and depth into one word: fewer than 2^27 slots, depth <= 31

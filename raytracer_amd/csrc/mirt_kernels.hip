@@ -396,6 +396,10 @@ __device__ __forceinline__ uint32_t membership(const DScene& S, const RayCtx& r,
 #ifndef STACK_LDS_REFILL
 #define STACK_LDS_REFILL 18
 #endif
+// k_frame keeps its waves' record tables in LDS as well and has one stack entry less for it
+#ifndef STACK_LDS_FRAME
+#define STACK_LDS_FRAME (STACK_LDS > 17 ? 17 : STACK_LDS)
+#endif
 #ifndef MIRT_BATCH_WAVES
 #define MIRT_BATCH_WAVES 7
 #endif
@@ -1324,13 +1328,17 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DFrame F, uint8_t* __restrict
 // lets a wave gather its hits while its neighbours do the same.
 // At the end of a frame, waves working side by side on little beat fewer waves working on more.
 #define FRAME_SLOT_MASK ((1u << FRAME_SLOT_BITS) - 1u)
+#define FRAME_RECORDS 128u // hit records of a wave: fewer than 128 paths are under way in a wave at any time (its list + its batch)
 #define FRAME_EMPTY 0xffffffffu
 
-template <int MODE, bool OVF, bool SHARE>
+template <int MODE, bool OVF, bool SHARE, bool RECORDS>
 __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIRT_FRAME_WAVES))) void k_frame(DScene S, DFrame F, uint8_t* __restrict__ out) {
-	__shared__ __align__(8) uint32_t s_stack[STACK_LDS * FRAME_BLOCK];
+	constexpr int NLDS = RECORDS ? STACK_LDS_FRAME : STACK_LDS; // (the record tables take the place of one stack entry)
+	__shared__ __align__(8) uint32_t s_stack[NLDS * FRAME_BLOCK];
 	__shared__ uint32_t s_list[FRAME_BLOCK / WAVE][128];
-	LdsStack<OVF, STACK_LDS, FRAME_BLOCK> stk;
+	__shared__ uint8_t s_free[FRAME_BLOCK / WAVE][FRAME_RECORDS];
+	__shared__ uint32_t s_slotOf[FRAME_BLOCK / WAVE][FRAME_RECORDS]; // [record of the wave] the pixel slot of the path that holds it
+	LdsStack<OVF, NLDS, FRAME_BLOCK> stk;
 	stk.lds = s_stack + threadIdx.x;
 	stk.ovf = OVF ? F.ovf + ((size_t)blockIdx.x * FRAME_BLOCK + threadIdx.x) : nullptr;
 	stk.ovfStride = F.ovfStride;
@@ -1338,6 +1346,21 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 	const unsigned long long ltMask = (1ull << lane) - 1ull;
 	uint32_t* myList = s_list[threadIdx.x >> 6];
 	uint32_t nbuf = 0;            // entries in the list: fewer than 64 before a batch, fewer than 128 after
+	// Where per-path data lives (F.hitO/hitD/hitN[i], F.litL[depth][i]).  RECORDS = false: i = the path's pixel slot -- the
+	// arrays are as long as the image has slots (1.2 GB for 3840x2160 at maxdepth 5), nothing has to be managed, and the list
+	// entries hold the slot.  RECORDS = true: i = one of FRAME_RECORDS hit records of this wave, taken when a camera ray hits and
+	// given back when its path ends (free records: a stack of numbers in LDS; the path's pixel slot waits in LDS too), so a
+	// frame's working memory is sized by the waves of the launch (136 MB at maxdepth 5) whatever the image -- for callers who
+	// are short of memory and for the entry point that allocates nothing.  It costs 3 % of the frame rate (Stanford dragon
+	// 13.1 against 13.5 Grays/s on the same machine: about a hundred more instructions per round of 64 rays, and a frame has
+	// 200 000 rounds), which is why it is not the default.
+	uint8_t* myFree = s_free[threadIdx.x >> 6];
+	uint32_t* slotOf = s_slotOf[threadIdx.x >> 6];
+	uint32_t nFree = FRAME_RECORDS; // (uniform)
+	if (RECORDS) {
+		myFree[lane] = (uint8_t)lane;
+		myFree[lane + 64] = (uint8_t)(lane + 64);
+	}
 	const bool reflections = (F.features & F_REFLECTIONS) != 0;
 	const bool shadows = (F.features & F_SHADOWS) != 0;
 	const uint32_t last = reflections ? (uint32_t)S.maxDepth : 0u; // deepest hit a path can have (main.cpp:177)
@@ -1352,6 +1375,8 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 	const uint32_t nWaves = gridDim.x * (FRAME_BLOCK / WAVE);
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (FRAME_BLOCK / WAVE) + (threadIdx.x >> 6));
 	const uint32_t nBatches = (F.nSlots + 63u) >> 6;
+	const uint32_t recBase = RECORDS ? wave * FRAME_RECORDS : 0u; // this wave's records
+	const uint32_t recStride = RECORDS ? F.nRec : F.nSlots;       // entries of the per-path arrays
 	// The counter block of the NEXT frame on this stream is cleared here, by one wave (nothing else in this launch touches
 	// it, and the next frame starts when this launch has ended): no clear has to be queued in front of a frame.
 	if (wave == 0u && F.countersNext) {
@@ -1383,7 +1408,7 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 	enum { ROUND_PRIMARY, ROUND_LIGHT, ROUND_REFLECT };
 	int round = ROUND_PRIMARY;
 	uint32_t li = 0;              // the light of ROUND_LIGHT
-	uint32_t entry = FRAME_EMPTY; // this lane's hit of the current batch (slot | depth << 27), or none
+	uint32_t entry = FRAME_EMPTY; // this lane's hit of the current batch (pixel slot, or record of the wave, | depth << 27), or none
 	uint32_t tag = 0;             // ROUND_PRIMARY: this lane's slot
 	// (the hit's light sum so far, main.cpp:204-253, and its material index wait in F.litL while the rays are walked: four
 	// registers less to carry through the walk)
@@ -1439,10 +1464,10 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 					nbuf = 0;
 				}
 				if (entry != FRAME_EMPTY) {
-					const uint32_t matIndex = info_of(S, __float_as_uint(F.hitN[entry & FRAME_SLOT_MASK].w)).y;
+					const uint32_t matIndex = info_of(S, __float_as_uint(F.hitN[recBase + (entry & FRAME_SLOT_MASK)].w)).y;
 					const float4* mat = S.materials + (size_t)matIndex * 4;
 					const f3 sum = F3(mat[3]) + F3(mat[2]);                  // main.cpp:204: ambient + emission
-					F.litL[(size_t)(entry >> FRAME_SLOT_BITS) * F.nSlots + (entry & FRAME_SLOT_MASK)] = make_float4(sum.x, sum.y, sum.z, __uint_as_float(matIndex));
+					F.litL[(size_t)(entry >> FRAME_SLOT_BITS) * recStride + recBase + (entry & FRAME_SLOT_MASK)] = make_float4(sum.x, sum.y, sum.z, __uint_as_float(matIndex));
 				}
 				inBatch = true;
 				li = 0;
@@ -1450,10 +1475,10 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 			}
 		}
 		const bool has = inBatch && entry != FRAME_EMPTY;
-		const uint32_t slot = entry & FRAME_SLOT_MASK, depth = has ? entry >> FRAME_SLOT_BITS : 0u;
+		const uint32_t rec = recBase + (entry & FRAME_SLOT_MASK), depth = has ? entry >> FRAME_SLOT_BITS : 0u;
 		if (inBatch && round == ROUND_LIGHT) {
 			if (has && shadows) {                                            // main.cpp:208-224
-				const float4 ho = F.hitO[slot], hd = F.hitD[slot];
+				const float4 ho = F.hitO[rec], hd = F.hitD[rec];
 				const f3 po = F3(ho), pd = F3(hd);
 				const f3 P = po + normalize3(pd) * hd.w;                     // Camera.cpp:26-28
 				const float4 ll = S.lights[li * 2];
@@ -1463,7 +1488,7 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 				walk = true;
 				// a query whose light term is multiplied by exact zeros is answered without a walk (see item_ray)
 				if (S.shadowCull && F.debug == D_NONE) {
-					const f3 N = F3(F.hitN[slot]);
+					const f3 N = F3(F.hitN[rec]);
 					const bool kd0 = !(F.features & F_DIFFUSE) || dot3(normalize3(N), normalize3(L)) <= 0.0f;
 					bool ks0 = !(F.features & F_SPECULAR);
 					if (!ks0) {
@@ -1482,11 +1507,11 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 				// The reference traces the reflection ray even when its weight mat.specular is zero in all channels
 				// (main.cpp:190), and so does MIRT_TRACE_EXACT: 0 x (what comes back) is not 0 when an inf or a NaN comes back.
 				// MIRT_TRACE_FAST leaves that case aside and ends the path here.
-				const float4 sp = S.materials[(size_t)__float_as_uint(F.litL[(size_t)depth * F.nSlots + slot].w) * 4 + 1];
+				const float4 sp = S.materials[(size_t)__float_as_uint(F.litL[(size_t)depth * recStride + rec].w) * 4 + 1];
 				if (sp.x == 0.0f && sp.y == 0.0f && sp.z == 0.0f) { spawn = false; ++nReflSkipped; }
 			}
 			if (spawn) {
-				const float4 ho = F.hitO[slot], hd = F.hitD[slot], hn = F.hitN[slot];
+				const float4 ho = F.hitO[rec], hd = F.hitD[rec], hn = F.hitN[rec];
 				const f3 pd = F3(hd), N = F3(hn);
 				const f3 P = F3(ho) + normalize3(pd) * hd.w;
 				w.start(S, P, normalize3(pd - N * (2.0f * dot3(pd, N))), -1.0f);  // main.cpp:188
@@ -1552,29 +1577,35 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 				}
 			}
 			const bool newHit = hit && !red;
+			const unsigned long long hm = __builtin_amdgcn_ballot_w64(newHit);
+			uint32_t r = tag; // where the new path's data goes: its pixel slot, or (RECORDS) a record taken from the wave's stack
+			if (RECORDS && newHit) { // (there is always one: fewer than FRAME_RECORDS paths are under way)
+				r = myFree[nFree - 1u - (uint32_t)__popcll(hm & ltMask)];
+				slotOf[r] = tag;
+			}
 			if (newHit) {
 				const f3 n = hit_normal(S, w.r, w.best.ref);
-				F.hitO[tag] = make_float4(w.r.o.x, w.r.o.y, w.r.o.z, 0.0f);
-				F.hitD[tag] = make_float4(w.r.d.x, w.r.d.y, w.r.d.z, w.best.dist);
-				F.hitN[tag] = make_float4(n.x, n.y, n.z, __uint_as_float(w.best.ref));
+				F.hitO[recBase + r] = make_float4(w.r.o.x, w.r.o.y, w.r.o.z, 0.0f);
+				F.hitD[recBase + r] = make_float4(w.r.d.x, w.r.d.y, w.r.d.z, w.best.dist);
+				F.hitN[recBase + r] = make_float4(n.x, n.y, n.z, __uint_as_float(w.best.ref));
 			}
 			const uint32_t nh = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(hit));
 			nHit0 += nh;
 			nHitAll += nh;
 			if (last == 0u) nHitLast += nh;
-			const unsigned long long hm = __builtin_amdgcn_ballot_w64(newHit);
 			if (hm) {
-				if (newHit) myList[nbuf + (uint32_t)__popcll(hm & ltMask)] = tag; // depth 0
+				if (newHit) myList[nbuf + (uint32_t)__popcll(hm & ltMask)] = r; // depth 0
 				nbuf += (uint32_t)__popcll(hm);
+				if (RECORDS) nFree -= (uint32_t)__popcll(hm);
 			}
 			continue;
 		}
 		if (round == ROUND_LIGHT) {
 			if (has) {
-				const float4 ho = F.hitO[slot], hd = F.hitD[slot], hn = F.hitN[slot];
+				const float4 ho = F.hitO[rec], hd = F.hitD[rec], hn = F.hitN[rec];
 				const f3 po = F3(ho);
 				const f3 P = po + normalize3(F3(hd)) * hd.w;
-				float4* lit = F.litL + (size_t)depth * F.nSlots + slot;
+				float4* lit = F.litL + (size_t)depth * recStride + rec;
 				const float4 l4 = *lit;
 				f3 sum = F3(l4);
 				shade_light(S, F.features, F.debug, po, P, F3(hn), S.materials + (size_t)__float_as_uint(l4.w) * 4, li, shadows,
@@ -1587,21 +1618,22 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 		// ROUND_REFLECT: the hit's light sum is complete (in F.litL)
 		if (hit) {
 			const f3 n = hit_normal(S, w.r, w.best.ref);
-			F.hitO[slot] = make_float4(w.r.o.x, w.r.o.y, w.r.o.z, 0.0f);
-			F.hitD[slot] = make_float4(w.r.d.x, w.r.d.y, w.r.d.z, w.best.dist);
-			F.hitN[slot] = make_float4(n.x, n.y, n.z, __uint_as_float(w.best.ref));
+			F.hitO[rec] = make_float4(w.r.o.x, w.r.o.y, w.r.o.z, 0.0f);
+			F.hitD[rec] = make_float4(w.r.d.x, w.r.d.y, w.r.d.z, w.best.dist);
+			F.hitN[rec] = make_float4(n.x, n.y, n.z, __uint_as_float(w.best.ref));
 		}
 		if (has && !hit) {
 			// the path ends here: fold its light sums back to front, C = L_k + S_k * C (main.cpp:190), starting from Color()
 			// beyond the last hit (main.cpp:199) or the black background (main.cpp:124); quantise (Color.cpp:13-23)
 			f3 C = F3(0, 0, 0);
 			for (int k = (int)depth; k >= 0; --k) {
-				const float4 L = F.litL[(size_t)k * F.nSlots + slot];
+				const float4 L = F.litL[(size_t)k * recStride + rec];
 				const float4 Sp = S.materials[(size_t)__float_as_uint(L.w) * 4 + 1];
 				if (reflections || k > 0) C = F3(L) + F3(Sp) * C;
 				else C = F3(L); // main.cpp:193
 			}
 			uint32_t px, py, inTile;
+			const uint32_t slot = RECORDS ? slotOf[entry & FRAME_SLOT_MASK] : (entry & FRAME_SLOT_MASK);
 			if (slot_to_pixel(F, slot, px, py, inTile)) {
 				const size_t o = out_offset(F, slot, px, py, inTile);
 				out[o] = quantise(C.z);     // B  main.cpp:154
@@ -1613,8 +1645,14 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 		if (hm) {
 			nHitAll += (uint32_t)__popcll(hm);
 			nHitLast += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(hit && depth + 1u == last));
-			if (hit) myList[nbuf + (uint32_t)__popcll(hm & ltMask)] = slot | ((depth + 1u) << FRAME_SLOT_BITS);
+			if (hit) myList[nbuf + (uint32_t)__popcll(hm & ltMask)] = (entry & FRAME_SLOT_MASK) | ((depth + 1u) << FRAME_SLOT_BITS);
 			nbuf += (uint32_t)__popcll(hm);
+		}
+		// the records of the paths that ended go back on the stack
+		const unsigned long long em = RECORDS ? __builtin_amdgcn_ballot_w64(has && !hit) : 0ull;
+		if (RECORDS && em) {
+			if (has && !hit) myFree[nFree + (uint32_t)__popcll(em & ltMask)] = (uint8_t)(entry & FRAME_SLOT_MASK);
+			nFree += (uint32_t)__popcll(em);
 		}
 		inBatch = false;
 	}
