@@ -129,8 +129,11 @@ typedef struct mirt_scene_desc {
  *   EXACT:   primitives are enumerated through the library's own hierarchy over the primitives; a candidate counts only
  *            if one of the Partition leaves that hold it passes AABB::intersect (AABB.cpp:53-72, evaluated exactly).
  *            Same result as Partition::intersect (Partition.cpp:35-53) including its tie-breaks.
- *   FAST:    as EXACT without the leaf-box check: differs only for a hit the reference's tree would not have reached;
- *            also ends a path at a material whose specular weight is zero instead of tracing the weightless reflection.
+ *   FAST:    as EXACT without the leaf-box check: differs only for a hit the reference's tree would not have reached, and
+ *            where two primitives are hit at the same distance (it takes the lower primitive number; the reference the one
+ *            its tree visits first); also ends a path at a material whose specular weight is zero instead of tracing the
+ *            weightless reflection.  The triangle test is still the reference's (Triangle.cpp:147-171: plane hit and three
+ *            signed-area edge tests), NOT Moeller-Trumbore: the mode relaxes which candidates count, never the arithmetic.
  *   REFWALK: walks the Partition tree that was handed over, box by box (cross-check and fallback; slow). */
 #define MIRT_TRACE_EXACT 0u
 #define MIRT_TRACE_FAST 1u

@@ -558,6 +558,10 @@ struct Walker {
 		if (key[3] != 0xffffffffu) { stk.push(sp, ref[3]); ++sp; }
 		if (key[2] != 0xffffffffu) { stk.push(sp, ref[2]); ++sp; }
 		if (key[1] != 0xffffffffu) { stk.push(sp, ref[1]); ++sp; }
+		// (Measured and dropped: asking for the child that will be popped next right here, with a load that lands in a corner of
+		// LDS nobody reads (global_load_lds), so that it is on its way through the caches while the nearer subtree is walked:
+		// the 10-million-triangle scene -3.5 %, the Stanford dragon -8 %.  A pushed child that the walk ends or culls before
+		// it is popped was fetched for nothing, and every step issues one more request.)
 	}
 
 	// Tests the first record of leaf reference `lf` against the ray and updates the best hit.  Returns true if the walk
@@ -582,6 +586,16 @@ struct Walker {
 		const bool tie = !any && dist == best.dist && ref != best.ref;
 		const bool cand = any ? (dist < limit) : (dist < best.dist || tie);
 		if (!cand) return false;
+		if (MODE == MODE_FAST && tie) {
+			// Two primitives at the same distance (the shared edge of two triangles).  The reference takes the one it visits
+			// first (Partition.h:33, Partition.cpp:47), which MIRT_TRACE_EXACT settles with the visiting ranks of the leaves.
+			// Without them: the lower primitive number -- the order inside a leaf, so the reference's choice whenever one
+			// leaf holds both, which is the usual case.
+			const uint32_t idNew = sph ? S.sphInfo[idx].x : S.triInfo[idx].x;
+			const uint32_t idOld = (best.ref & PRIM_SPHERE) ? S.sphInfo[best.ref & ~PRIM_SPHERE].x : S.triInfo[best.ref].x;
+			if (idNew < idOld) best.ref = ref;
+			return false;
+		}
 		uint32_t pos = 0;
 		if (MODE == MODE_EXACT) {
 			if (!STRICT) {

@@ -115,9 +115,11 @@ def test_fast_mode_within_north_star_tolerance(name, dev_scenes, goldens):
     s = dev_scenes(name)
     ids, dist = s.trace_primary_ids(w, h, trace_mode=_capi.TRACE_FAST)
     # FAST skips the leaf-membership check, which is also what supplies the reference's tie-break rank: where two
-    # primitives are hit at bit-identical distance (the shared diagonal of a quad) it may name the other one.
+    # primitives are hit at bit-identical distance (the shared diagonal of a quad) it takes the lower primitive number,
+    # the reference's choice whenever one leaf holds both.
     same = ids == g["prim_id"]
-    assert same.mean() >= 0.995
+    print(name, "FAST ids equal on %.5f of the primary rays" % same.mean())
+    assert same.mean() >= 0.999
     assert np.array_equal(bits(dist), bits(g["dist"]))
     img, _ = s.render(w, h, trace_mode=_capi.TRACE_FAST)
     ok = (np.abs(img.astype(int) - g["bgr_f15"].astype(int)).max(axis=2) <= 1).mean()
