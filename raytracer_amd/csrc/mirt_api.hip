@@ -986,6 +986,54 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 	F.divArea = make_div(tileW * tileH);
 	F.divSbx = make_div(tileW >> 3);
 	F.divTilesX = make_div(g.tilesX);
+	// A camera ray that misses the bounds of the whole scene hits nothing (Walker::start ends it at once), and with the
+	// image cleared beforehand its pixel needs no visit at all.  So a whole-image frame covers only the tiles that touch the
+	// screen rectangle of the scene's bounds: the eight corners of the hierarchy's root box (padded primitive bounds) are
+	// projected the way Camera::createRayToPixel (Camera.cpp:15-24) maps pixels to directions, in double, and the rectangle is
+	// widened by two pixels before it is rounded out to tiles -- orders of magnitude more than the float rounding of a ray's
+	// direction.  A corner at or behind the eye plane leaves the frame whole.  (The Stanford dragon's rectangle holds 43 %
+	// of its 3840x2160 frame: 14.4 against 13.8 Grays/s over 20 frames, 7680x4320 17.9 against 17.0.)  MIRT_SCREEN_RECT=0: every tile.
+	F.rectTx0 = F.rectTy0 = 0;
+	uint32_t rectTw = 0, rectTh = 0;
+	{
+		const char* re = getenv("MIRT_SCREEN_RECT"); // (read per frame: tests switch it)
+		const char* cik = getenv("MIRT_CLEAR_IN_KERNEL");
+		const bool on = !(re && *re == '0') && !(cik && *cik == '1');
+		const DScene& ds = s->ds;
+		if (on && single && !packed && p->tile_stride == 1 && ds.bvhRoot != BVH_DONE) {
+			double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+			bool ok = true;
+			const double W = p->width, H = p->height, T = ds.cam.tanHalf, aspect = (double)(float)((float)(int)p->width / (int)p->height);
+			for (int corner = 0; corner < 8 && ok; ++corner) {
+				double v[3];
+				for (int k = 0; k < 3; ++k) v[k] = (double)((corner >> k) & 1 ? ds.bvhMax[k] : ds.bvhMin[k]) - ds.cam.eye[k];
+				const double a = v[0] * ds.cam.u[0] + v[1] * ds.cam.u[1] + v[2] * ds.cam.u[2];
+				const double b = v[0] * ds.cam.v[0] + v[1] * ds.cam.v[1] + v[2] * ds.cam.v[2];
+				const double c = -(v[0] * ds.cam.w[0] + v[1] * ds.cam.w[1] + v[2] * ds.cam.w[2]); // along the viewing direction
+				const double len = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+				if (!(c > 1e-3 * len) || !(T > 1e-6) || !std::isfinite(c)) { ok = false; break; }
+				// dir = alpha u + beta v - w (Camera.cpp:21): the corner lies on the ray with alpha = a / c, beta = b / c
+				const double px = (a / c) / (T * aspect) * (W / 2) + W / 2, py = H / 2 - (b / c) / T * (H / 2);
+				if (!std::isfinite(px) || !std::isfinite(py)) { ok = false; break; }
+				x0 = std::min(x0, px); x1 = std::max(x1, px); y0 = std::min(y0, py); y1 = std::max(y1, py);
+			}
+			if (ok) {
+				x0 -= 2.5; y0 -= 2.5; x1 += 2.5; y1 += 2.5; // pixel centres lie at +0.5
+				const double tx0 = std::max(0.0, floor(x0 / tileW)), ty0 = std::max(0.0, floor(y0 / tileH));
+				const double tx1 = std::min((double)g.tilesX - 1, floor(x1 / tileW)), ty1 = std::min((double)g.tilesY - 1, floor(y1 / tileH));
+				if (tx1 >= tx0 && ty1 >= ty0) {
+					F.rectTx0 = (uint32_t)tx0; F.rectTy0 = (uint32_t)ty0;
+					rectTw = (uint32_t)(tx1 - tx0) + 1; rectTh = (uint32_t)(ty1 - ty0) + 1;
+				}
+				else { rectTw = 1; rectTh = 1; F.rectTx0 = F.rectTy0 = 0; } // nothing of the scene on the screen: one tile keeps the launch simple
+			}
+		}
+	}
+	if (rectTw) {
+		F.nSlots = rectTw * rectTh * tileW * tileH;
+		F.nTilesLocal = rectTw * rectTh;
+		F.divTilesX = make_div(rectTw);
+	}
 	// bytes of tiles that are not rendered must stay untouched in the full-image layout, so only clear when all are
 	F.preCleared = (packed || p->tile_stride == 1) ? 1u : 0u;
 	F.wideClear = (((uintptr_t)d_out & 3u) == 0 && (packed || (p->width & 3u) == 0)) ? 1u : 0u;
@@ -998,7 +1046,7 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 	F.batchMul = 0;
 	if (single) {
 		static const int parts = []() { const char* e = getenv("MIRT_BATCH_STRIDE"); const int v = e ? atoi(e) : 128; return v < 0 ? 0 : v; }(); // (a number: that fraction of the frame)
-		const uint64_t nb = (g.nSlots + 63) / 64;
+		const uint64_t nb = ((uint64_t)F.nSlots + 63) / 64;
 		if (parts && nb >= 16384) {
 			uint64_t m = (nb / (uint64_t)parts) | 1u;
 			auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
@@ -1040,18 +1088,19 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 	if (single) {
 		// Waves of the launch per SIMD.  A frame alone wants every place on the GPU (7): its time is the chain of rounds
 		// behind its last batches, and more waves make every chain shorter.  A frame that shares the GPU with frames on
-		// other streams wants waves with enough batches each to gather their hits into full rounds -- about 64 batches of
-		// 64 pixel slots per wave.  Measured, 16 hardware queues: a whole 4K frame 0.894 ms per frame on 2 waves per SIMD
-		// against 0.933 on 7 (and 0.953 on 1); half of it (one rank of two) 0.452 on 1 against 0.477 on 3; an eighth 0.138
-		// on 1 against 0.165 on 7; a 1080p frame 0.303 against 0.346.  MIRT_FRAME_GRID=n fixes the number.
+		// other streams wants waves with enough batches each to gather their hits into full rounds -- about 32 batches of
+		// 64 pixel slots per wave, never fewer than two waves per SIMD.  Measured with eight frames in flight on 16 hardware
+		// queues, Grays/s over 20 frames by waves per SIMD -- Stanford dragon 3840x2160 (56 000 batches inside the screen
+		// rectangle of the scene): 1: 13.4, 2: 14.4, 3: 14.0, 7: 13.4; 7680x4320 (233 000): 2: 17.5, 4-7: 17.8; 1920x1080
+		// (15 000): 1: 9.4, 2: 9.85, 3: 9.9; 1200 spheres 1920x1080 (32 000): 1: 15.8, 2: 16.5, 3: 15.6; Cornell box 640x480
+		// (4 800): 1: 13.3, 2: 14.5, 3: 14.1.  MIRT_FRAME_GRID=n fixes the number.
 		static const int gwEnv = []() { const char* e = getenv("MIRT_FRAME_GRID"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= MIRT_FRAME_WAVES ? v : 0; }();
 		int gw = MIRT_FRAME_WAVES;
 		if (gwEnv) gw = gwEnv;
 		else if (othersInFlight >= 3) {
-			const uint64_t nBatches = ((uint64_t)g.nSlots + 63u) / 64u, perWave = (uint64_t)s->numCUs * 4u * 64u;
+			const uint64_t nBatches = ((uint64_t)F.nSlots + 63u) / 64u, perWave = (uint64_t)s->numCUs * 4u * 32u;
 			const uint64_t want = (nBatches + perWave / 2) / perWave;
-			gw = want < 1 ? 1 : (want > (uint64_t)MIRT_FRAME_WAVES ? MIRT_FRAME_WAVES : (int)want);
-			if (nBatches < 8192u) gw = 2; // (a 640x480 frame: 2 beats 1 and 7 by 3 %)
+			gw = want < 2 ? 2 : (want > (uint64_t)MIRT_FRAME_WAVES ? MIRT_FRAME_WAVES : (int)want);
 		}
 		const int grid = s->numCUs * (gw < GRID_BLOCKS_PER_CU ? gw : GRID_BLOCKS_PER_CU) * (BLOCK / FRAME_BLOCK); // every block resident at once
 		if (c) c->nLaunches = 0;

@@ -721,8 +721,8 @@ __device__ __forceinline__ bool slot_to_pixel(const DFrame& F, uint32_t slot, ui
 	const uint32_t tx = sbxi * 8 + (l & 7), ty = sby * 8 + (l >> 3);
 	const uint32_t k = F.firstTile + lt * F.tileStride;
 	const uint32_t ky = fast_div(k, F.divTilesX), kx = k - ky * F.divTilesX.d;
-	px = kx * F.tileW + tx;
-	py = ky * F.tileH + ty;
+	px = (kx + F.rectTx0) * F.tileW + tx;
+	py = (ky + F.rectTy0) * F.tileH + ty;
 	inTile = ty * F.tileW + tx;
 	return px < F.width && py < F.height;
 }
