@@ -313,6 +313,14 @@ struct PngPipe {
 	}
 };
 
+// The 8x8 pixel blocks of one frame geometry that can see the scene (see visible_blocks), on the device.
+struct BlockList {
+	uint32_t width, height, tileW, tileH, first, stride, packed;
+	DevBuf list;
+	uint32_t count = 0;
+	bool all = false; // every block is visible (or the scene reaches behind the eye plane): no list is used
+};
+
 struct mirt_scene {
 	int device = 0;
 	int numCUs = 256;
@@ -340,6 +348,10 @@ struct mirt_scene {
 	CopyBack* copyBack = nullptr;
 	PngPipe* png = nullptr;
 	int copyThreads = 6;
+	// Boxes that together hold every primitive (a breadth-first cut through the hierarchy, 6 floats each), and the lists of
+	// visible 8x8 pixel blocks made from them, one per frame geometry that was rendered (visible_blocks)
+	std::vector<float> cutBoxes;
+	std::vector<BlockList*> blockLists;
 	uint32_t framesHint = 0;  // frames the caller says it keeps in flight (mirt_set_frames_in_flight); 0, 1: not said
 	bool singleLaunch = true; // frames run as one launch (k_frame) where that kernel applies; MIRT_SINGLE_LAUNCH=0: one launch per depth
 };
@@ -962,6 +974,131 @@ int frame_checks(mirt_scene* s, const mirt_render_params* p, void* d_out, size_t
 	return MIRT_OK;
 }
 
+// Boxes that together hold every primitive: a breadth-first cut through the 4-wide hierarchy (`wide`: 16 words per node,
+// layout in mirt_device.h), opened level by level until there are about `want` of them.  A child's box is decoded from
+// its parent's quantised bytes, i.e. it is the box the walk itself tests (it contains the padded primitive bounds).
+void cut_boxes(const uint32_t* wide, size_t nNodes, uint32_t root, const float rootLo[3], const float rootHi[3], size_t want, std::vector<float>& out) {
+	struct Item { uint32_t ref; float b[6]; };
+	std::vector<Item> level, next;
+	out.clear();
+	Item r;
+	r.ref = root;
+	for (int k = 0; k < 3; ++k) { r.b[k] = rootLo[k]; r.b[3 + k] = rootHi[k]; }
+	if (root == BVH_DONE) return; // an empty scene: no box, nothing is visible
+	level.push_back(r);
+	for (;;) {
+		size_t interior = 0;
+		for (const Item& it : level) interior += !(it.ref & BVH_LEAF) && it.ref < nNodes;
+		if (interior == 0 || level.size() >= want) break;
+		next.clear();
+		for (const Item& it : level) {
+			if ((it.ref & BVH_LEAF) || it.ref >= nNodes) { next.push_back(it); continue; }
+			const uint32_t* w = wide + (size_t)it.ref * 16;
+			float org[3], scale[3];
+			for (int k = 0; k < 3; ++k) {
+				memcpy(&org[k], &w[k], 4);
+				scale[k] = ldexpf(1.0f, (int)(int8_t)((w[3] >> (8 * k)) & 0xffu));
+			}
+			for (int c = 0; c < 4; ++c) {
+				const uint32_t ref = w[10 + c];
+				if (ref == BVH_DONE) continue;
+				Item ch;
+				ch.ref = ref;
+				for (int k = 0; k < 3; ++k) {
+					ch.b[k] = org[k] + (float)((w[4 + k] >> (8 * c)) & 0xffu) * scale[k];
+					ch.b[3 + k] = org[k] + (float)((w[7 + k] >> (8 * c)) & 0xffu) * scale[k];
+				}
+				next.push_back(ch);
+			}
+		}
+		level.swap(next);
+	}
+	out.reserve(level.size() * 6);
+	for (const Item& it : level) out.insert(out.end(), it.b, it.b + 6);
+}
+
+// boxes of the cut (MIRT_CUT_BOXES sets another number)
+size_t cut_box_count() {
+	const char* e = getenv("MIRT_CUT_BOXES");
+	const long v = e ? atol(e) : 0;
+	return v >= 1 && v <= (1l << 24) ? (size_t)v : 4096;
+}
+
+// Which 8x8 pixel blocks of a frame can see the scene?  Every box of the scene's cut is projected the way
+// Camera::createRayToPixel (Camera.cpp:15-24) maps pixels to directions -- its eight corners, in double -- and the blocks
+// under the corners' bounding rectangle, widened by 2.5 pixels (orders of magnitude more than the float rounding of a
+// ray's direction), are marked.  A camera ray through an unmarked block misses every box, so it misses every primitive:
+// the block's pixels are black, and the frame's clear has already made them so.  A box with a corner at or behind the
+// eye plane has no such rectangle: then every block is visited.  Lists are kept per frame geometry (a scene's camera is
+// fixed); a block's number is its slot number / 64.  Returns NULL when every block has to be visited.
+// create = false: only a list that exists already is used (the entry point that allocates nothing).
+const BlockList* visible_blocks(mirt_scene* s, const mirt_render_params* p, const TileGeom& g, uint32_t tileW, uint32_t tileH, bool packed, bool create) {
+	for (BlockList* b : s->blockLists)
+		if (b->width == p->width && b->height == p->height && b->tileW == tileW && b->tileH == tileH && b->first == p->first_tile && b->stride == p->tile_stride && b->packed == (packed ? 1u : 0u))
+			return b->all ? nullptr : b;
+	if (!create) return nullptr;
+	if (s->blockLists.size() >= 32) { // (callers that render ever new sizes: start over)
+		(void)hipDeviceSynchronize();
+		for (BlockList* b : s->blockLists) { b->list.release(); delete b; }
+		s->blockLists.clear();
+	}
+	BlockList* bl = new (std::nothrow) BlockList();
+	if (!bl) return nullptr;
+	bl->width = p->width; bl->height = p->height; bl->tileW = tileW; bl->tileH = tileH; bl->first = p->first_tile; bl->stride = p->tile_stride; bl->packed = packed ? 1u : 0u;
+	s->blockLists.push_back(bl);
+	bl->all = true;
+	const DScene& ds = s->ds;
+	const uint64_t nBlocks = g.nSlots / 64;
+	if (nBlocks == 0 || nBlocks > (1ull << 31)) return nullptr;
+	std::vector<uint8_t> mark(nBlocks, 0);
+	const double W = p->width, H = p->height, T = ds.cam.tanHalf, aspect = (double)((float)(int)p->width / (int)p->height);
+	if (!(T > 1e-6)) return nullptr;
+	const uint32_t sbx = tileW / 8, perTile = sbx * (tileH / 8);
+	for (size_t i = 0; i + 6 <= s->cutBoxes.size(); i += 6) {
+		const float* b = &s->cutBoxes[i];
+		double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+		for (int corner = 0; corner < 8; ++corner) {
+			double v[3];
+			for (int k = 0; k < 3; ++k) v[k] = (double)((corner >> k) & 1 ? b[3 + k] : b[k]) - ds.cam.eye[k];
+			const double a = v[0] * ds.cam.u[0] + v[1] * ds.cam.u[1] + v[2] * ds.cam.u[2];
+			const double bb = v[0] * ds.cam.v[0] + v[1] * ds.cam.v[1] + v[2] * ds.cam.v[2];
+			const double c = -(v[0] * ds.cam.w[0] + v[1] * ds.cam.w[1] + v[2] * ds.cam.w[2]); // along the viewing direction
+			const double len = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+			if (!(c > 1e-3 * len) || !std::isfinite(c)) return nullptr; // at or behind the eye plane
+			// dir = alpha u + beta v - w (Camera.cpp:21): the corner lies on the ray with alpha = a / c, beta = b / c
+			const double px = (a / c) / (T * aspect) * (W / 2) + W / 2, py = H / 2 - (bb / c) / T * (H / 2);
+			if (!std::isfinite(px) || !std::isfinite(py)) return nullptr;
+			x0 = std::min(x0, px); x1 = std::max(x1, px); y0 = std::min(y0, py); y1 = std::max(y1, py);
+		}
+		x0 -= 2.5; y0 -= 2.5; x1 += 2.5; y1 += 2.5; // pixel centres lie at +0.5
+		if (x1 < 0 || y1 < 0 || x0 >= W || y0 >= H) continue;
+		const uint32_t bx0 = (uint32_t)(std::max(0.0, x0) / 8), bx1 = (uint32_t)(std::min(W - 1, x1) / 8);
+		const uint32_t by0 = (uint32_t)(std::max(0.0, y0) / 8), by1 = (uint32_t)(std::min(H - 1, y1) / 8);
+		for (uint32_t by = by0; by <= by1; ++by) {
+			const uint32_t ty = by * 8 / tileH, sy = (by * 8 % tileH) / 8;
+			for (uint32_t bx = bx0; bx <= bx1; ++bx) {
+				const uint32_t tx = bx * 8 / tileW, sx = (bx * 8 % tileW) / 8;
+				const uint64_t k = (uint64_t)ty * g.tilesX + tx;
+				if (k < p->first_tile || (k - p->first_tile) % p->tile_stride) continue; // another rank's tile
+				const uint64_t blk = (k - p->first_tile) / p->tile_stride * perTile + (uint64_t)sy * sbx + sx;
+				if (blk < nBlocks) mark[blk] = 1;
+			}
+		}
+	}
+	std::vector<uint32_t> list;
+	for (uint64_t i = 0; i < nBlocks; ++i) if (mark[i]) list.push_back((uint32_t)i);
+	if (list.size() == nBlocks) return nullptr; // everything is visible: no list needed
+	if (list.empty()) list.push_back(0);         // nothing is: one block keeps the launch simple
+	if (bl->list.ensure(list.size() * 4) != MIRT_OK || hipMemcpy(bl->list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+		(void)hipGetLastError();
+		return nullptr;
+	}
+	bl->count = (uint32_t)list.size();
+	bl->all = false;
+	if (getenv("MIRT_VERBOSE")) fprintf(stderr, "mirt: %ux%u: %zu of %llu pixel blocks can see the scene (%zu boxes)\n", p->width, p->height, list.size(), (unsigned long long)nBlocks, s->cutBoxes.size() / 6);
+	return bl;
+}
+
 // Puts one frame on the stream: clears, every launch of the frame.  mem[] are the arrays of frame_layout(); c may be NULL
 // (no per-launch profiling then).  Allocates nothing.
 int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const TileGeom& g, uint32_t tileW, uint32_t tileH, bool packed, bool single, bool records,
@@ -986,57 +1123,26 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 	F.divArea = make_div(tileW * tileH);
 	F.divSbx = make_div(tileW >> 3);
 	F.divTilesX = make_div(g.tilesX);
-	// A camera ray that misses the bounds of the whole scene hits nothing (Walker::start ends it at once), and with the
-	// image cleared beforehand its pixel needs no visit at all.  So a whole-image frame covers only the tiles that touch the
-	// screen rectangle of the scene's bounds: the eight corners of the hierarchy's root box (padded primitive bounds) are
-	// projected the way Camera::createRayToPixel (Camera.cpp:15-24) maps pixels to directions, in double, and the rectangle is
-	// widened by two pixels before it is rounded out to tiles -- orders of magnitude more than the float rounding of a ray's
-	// direction.  A corner at or behind the eye plane leaves the frame whole.  (The Stanford dragon's rectangle holds 43 %
-	// of its 3840x2160 frame: 14.4 against 13.8 Grays/s over 20 frames, 7680x4320 17.9 against 17.0.)  MIRT_SCREEN_RECT=0: every tile.
-	F.rectTx0 = F.rectTy0 = 0;
-	uint32_t rectTw = 0, rectTh = 0;
-	{
-		const char* re = getenv("MIRT_SCREEN_RECT"); // (read per frame: tests switch it)
-		const char* cik = getenv("MIRT_CLEAR_IN_KERNEL");
-		const bool on = !(re && *re == '0') && !(cik && *cik == '1');
-		const DScene& ds = s->ds;
-		if (on && single && !packed && p->tile_stride == 1 && ds.bvhRoot != BVH_DONE) {
-			double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
-			bool ok = true;
-			const double W = p->width, H = p->height, T = ds.cam.tanHalf, aspect = (double)(float)((float)(int)p->width / (int)p->height);
-			for (int corner = 0; corner < 8 && ok; ++corner) {
-				double v[3];
-				for (int k = 0; k < 3; ++k) v[k] = (double)((corner >> k) & 1 ? ds.bvhMax[k] : ds.bvhMin[k]) - ds.cam.eye[k];
-				const double a = v[0] * ds.cam.u[0] + v[1] * ds.cam.u[1] + v[2] * ds.cam.u[2];
-				const double b = v[0] * ds.cam.v[0] + v[1] * ds.cam.v[1] + v[2] * ds.cam.v[2];
-				const double c = -(v[0] * ds.cam.w[0] + v[1] * ds.cam.w[1] + v[2] * ds.cam.w[2]); // along the viewing direction
-				const double len = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-				if (!(c > 1e-3 * len) || !(T > 1e-6) || !std::isfinite(c)) { ok = false; break; }
-				// dir = alpha u + beta v - w (Camera.cpp:21): the corner lies on the ray with alpha = a / c, beta = b / c
-				const double px = (a / c) / (T * aspect) * (W / 2) + W / 2, py = H / 2 - (b / c) / T * (H / 2);
-				if (!std::isfinite(px) || !std::isfinite(py)) { ok = false; break; }
-				x0 = std::min(x0, px); x1 = std::max(x1, px); y0 = std::min(y0, py); y1 = std::max(y1, py);
-			}
-			if (ok) {
-				x0 -= 2.5; y0 -= 2.5; x1 += 2.5; y1 += 2.5; // pixel centres lie at +0.5
-				const double tx0 = std::max(0.0, floor(x0 / tileW)), ty0 = std::max(0.0, floor(y0 / tileH));
-				const double tx1 = std::min((double)g.tilesX - 1, floor(x1 / tileW)), ty1 = std::min((double)g.tilesY - 1, floor(y1 / tileH));
-				if (tx1 >= tx0 && ty1 >= ty0) {
-					F.rectTx0 = (uint32_t)tx0; F.rectTy0 = (uint32_t)ty0;
-					rectTw = (uint32_t)(tx1 - tx0) + 1; rectTh = (uint32_t)(ty1 - ty0) + 1;
-				}
-				else { rectTw = 1; rectTh = 1; F.rectTx0 = F.rectTy0 = 0; } // nothing of the scene on the screen: one tile keeps the launch simple
+	// bytes of tiles that are not rendered must stay untouched in the full-image layout, so only clear when all are
+	F.preCleared = (packed || p->tile_stride == 1) ? 1u : 0u;
+	F.blockList = nullptr;
+	F.nListed = 0;
+	F.wideClear = (((uintptr_t)d_out & 3u) == 0 && (packed || (p->width & 3u) == 0)) ? 1u : 0u;
+	// A camera ray that misses the scene's bounds hits nothing, and with the output cleared beforehand its pixel needs no
+	// visit at all: k_frame is handed the list of the 8x8 pixel blocks that can see the scene (visible_blocks).
+	uint32_t nBatchesFrame = (uint32_t)(((uint64_t)F.nSlots + 63u) / 64u);
+	const char* cikEarly = getenv("MIRT_CLEAR_IN_KERNEL");
+	if (single && F.preCleared && !(cikEarly && *cikEarly == '1')) {
+		const char* re = getenv("MIRT_BLOCK_LIST"); // (read per frame: tests switch it)
+		if (!(re && *re == '0')) {
+			const BlockList* bl = visible_blocks(s, p, g, tileW, tileH, packed, c != nullptr);
+			if (bl) {
+				F.blockList = (const uint32_t*)bl->list.p;
+				F.nListed = bl->count;
+				nBatchesFrame = bl->count;
 			}
 		}
 	}
-	if (rectTw) {
-		F.nSlots = rectTw * rectTh * tileW * tileH;
-		F.nTilesLocal = rectTw * rectTh;
-		F.divTilesX = make_div(rectTw);
-	}
-	// bytes of tiles that are not rendered must stay untouched in the full-image layout, so only clear when all are
-	F.preCleared = (packed || p->tile_stride == 1) ? 1u : 0u;
-	F.wideClear = (((uintptr_t)d_out & 3u) == 0 && (packed || (p->width & 3u) == 0)) ? 1u : 0u;
 	// The order of k_frame's batches.  In image order the blocks that see the scene come in long runs (the rows the object
 	// covers) between runs that see nothing, and all waves are in the same kind of run at the same time.  Stepping through
 	// the blocks with a stride of about 1/128 of the frame (made coprime to the number of blocks, so every block comes
@@ -1046,7 +1152,7 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 	F.batchMul = 0;
 	if (single) {
 		static const int parts = []() { const char* e = getenv("MIRT_BATCH_STRIDE"); const int v = e ? atoi(e) : 128; return v < 0 ? 0 : v; }(); // (a number: that fraction of the frame)
-		const uint64_t nb = ((uint64_t)F.nSlots + 63) / 64;
+		const uint64_t nb = nBatchesFrame;
 		if (parts && nb >= 16384) {
 			uint64_t m = (nb / (uint64_t)parts) | 1u;
 			auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
@@ -1098,7 +1204,7 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 		int gw = MIRT_FRAME_WAVES;
 		if (gwEnv) gw = gwEnv;
 		else if (othersInFlight >= 3) {
-			const uint64_t nBatches = ((uint64_t)F.nSlots + 63u) / 64u, perWave = (uint64_t)s->numCUs * 4u * 32u;
+			const uint64_t nBatches = nBatchesFrame, perWave = (uint64_t)s->numCUs * 4u * 32u;
 			const uint64_t want = (nBatches + perWave / 2) / perWave;
 			gw = want < 2 ? 2 : (want > (uint64_t)MIRT_FRAME_WAVES ? MIRT_FRAME_WAVES : (int)want);
 		}
@@ -1522,6 +1628,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		memcpy(bvhMax, bb.nodes[0].hi, 12);
 	}
 	up.push(s->bvh, bvhWide.data(), bvhWide.size() * 4);
+	cut_boxes(bvhWide.data(), bvhWide.size() / 16, bvhRoot, bvhMin, bvhMax, cut_box_count(), s->cutBoxes);
 	phase("hierarchy collapse");
 
 	// ---- the reference tree as it is (MODE_REFWALK) ------------------------------------------------------------------------
@@ -1680,6 +1787,8 @@ void mirt_scene_destroy(mirt_scene* s) {
 	s->copyBack = nullptr;
 	delete s->png;
 	s->png = nullptr;
+	for (BlockList* b : s->blockLists) { b->list.release(); delete b; }
+	s->blockLists.clear();
 	s->nodes.release(); s->leafs.release(); s->bvh.release(); s->memb.release(); s->tris.release(); s->triX.release(); s->triInfo.release();
 	s->spheres.release(); s->sphInfo.release(); s->materials.release(); s->lights.release(); s->hookOvf.release(); s->dbg.release();
 	for (FrameCtx* c : s->ctxs) {
@@ -1831,6 +1940,8 @@ int mirt_scene_load(const char* path, int device, mirt_scene** out, uint32_t use
 	bool ok = map.n - at >= sizeof s->ds + sizeof m;
 	int devErr = MIRT_OK;
 	std::string devMsg;
+	const uint8_t* wideAt = nullptr; // the hierarchy's nodes in the mapping
+	size_t wideBytes = 0;
 	{
 		Uploader up(device); // (also the first to touch the device: the runtime starts up beside the checksum)
 		if (ok) {
@@ -1851,6 +1962,7 @@ int mirt_scene_load(const char* path, int device, mirt_scene** out, uint32_t use
 			if (n > (1ull << 40) || (n % recordBytes[k] != 0 && n != 16)) { ok = false; why = "array size not a whole number of records"; break; }
 			if (map.n - at < n) { ok = false; break; }
 			up.push(*scene_buffers(s, k), map.p + at, n);
+			if (k == 2) { wideAt = map.p + at; wideBytes = (size_t)n; }
 			sum = sum_of(sum, map.p + at, n);
 			at += n;
 		}
@@ -1887,6 +1999,12 @@ int mirt_scene_load(const char* path, int device, mirt_scene** out, uint32_t use
 	s->nested = m.nested != 0; s->bvhDepth = m.bvhDepth; s->nLights = m.nLights; s->maxDepth = m.maxDepth;
 	s->wideDepth = m.wideDepth; s->refillMin = m.refillMin;
 	memcpy(s->diag, m.diag, sizeof m.diag);
+	if (wideAt && ((uintptr_t)wideAt & 3u) == 0)
+		cut_boxes((const uint32_t*)wideAt, wideBytes / 64, s->ds.bvhRoot, s->ds.bvhMin, s->ds.bvhMax, cut_box_count(), s->cutBoxes);
+	else if (s->ds.bvhRoot != BVH_DONE) { // (cannot happen with files this library wrote) the bounds of the whole scene
+		s->cutBoxes.assign(s->ds.bvhMin, s->ds.bvhMin + 3);
+		s->cutBoxes.insert(s->cutBoxes.end(), s->ds.bvhMax, s->ds.bvhMax + 3);
+	}
 	// How much of the traversal stack lies beyond LDS depends on THIS build's STACK_LDS, not on the build that wrote the
 	// file: derived again from the stack need of the hierarchy (diag[6]), exactly as mirt_scene_create does.
 	{

@@ -119,8 +119,8 @@ struct DFrame {
 	uint32_t refillMin;   // k_trace<REFILL>: parked lanes that trigger a refill
 	uint32_t preCleared;  // the output buffer and pathDepth were zeroed before the frame: missed primary rays store nothing (per-depth launches)
 	uint32_t wideClear;   // k_frame: every row of an 8x8 pixel block starts on a 4-byte boundary of the output (black blocks are written as words)
-	uint32_t rectTx0, rectTy0; // whole images only: the launch covers the tiles from (rectTx0, rectTy0) on, divTilesX.d tiles to a row --
-	                           // the screen rectangle of the scene's bounds; the pixels outside it are black and were cleared (0, 0: all tiles)
+	const uint32_t* blockList; // k_frame: the 8x8 pixel blocks (slot >> 6) the launch has to visit, ascending -- those that can see the
+	uint32_t nListed;          // scene at all; the others are black and were cleared.  NULL: every block of the frame
 	uint32_t batchMul;    // k_frame hands out 8x8 pixel block (b * batchMul) mod nBatches as its b-th batch (0: block b)
 	FastDiv divArea, divSbx, divTilesX; // tile area, 8x8 blocks per tile row, tiles per image row
 };

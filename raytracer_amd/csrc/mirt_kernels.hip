@@ -721,8 +721,8 @@ __device__ __forceinline__ bool slot_to_pixel(const DFrame& F, uint32_t slot, ui
 	const uint32_t tx = sbxi * 8 + (l & 7), ty = sby * 8 + (l >> 3);
 	const uint32_t k = F.firstTile + lt * F.tileStride;
 	const uint32_t ky = fast_div(k, F.divTilesX), kx = k - ky * F.divTilesX.d;
-	px = (kx + F.rectTx0) * F.tileW + tx;
-	py = (ky + F.rectTy0) * F.tileH + ty;
+	px = kx * F.tileW + tx;
+	py = ky * F.tileH + ty;
 	inTile = ty * F.tileW + tx;
 	return px < F.width && py < F.height;
 }
@@ -1388,7 +1388,7 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 	// frame alone ends 3 % later, and a 10-million-triangle scene loses 8 %.)
 	const uint32_t nWaves = gridDim.x * (FRAME_BLOCK / WAVE);
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (FRAME_BLOCK / WAVE) + (threadIdx.x >> 6));
-	const uint32_t nBatches = (F.nSlots + 63u) >> 6;
+	const uint32_t nBatches = F.blockList ? F.nListed : (F.nSlots + 63u) >> 6;
 	const uint32_t recBase = RECORDS ? wave * FRAME_RECORDS : 0u; // this wave's records
 	const uint32_t recStride = RECORDS ? F.nRec : F.nSlots;       // entries of the per-path arrays
 	// The counter block of the NEXT frame on this stream is cleared here, by one wave (nothing else in this launch touches
@@ -1452,7 +1452,8 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 				round = ROUND_PRIMARY;
 				pfirst = false;
 				// (batches are not handed out in image order: see where the host sets batchMul)
-				const uint32_t batch = F.batchMul ? (uint32_t)(((unsigned long long)pbatch * F.batchMul) % nBatches) : pbatch;
+				uint32_t batch = F.batchMul ? (uint32_t)(((unsigned long long)pbatch * F.batchMul) % nBatches) : pbatch;
+				if (F.blockList) batch = F.blockList[batch]; // (only the blocks that can see the scene are on the list)
 				tag = batch * 64u + (uint32_t)lane;
 				const uint32_t got = F.nSlots - batch * 64u < 64u ? F.nSlots - batch * 64u : 64u;
 				if ((uint32_t)lane < got) {

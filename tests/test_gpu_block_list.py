@@ -1,7 +1,8 @@
-"""GPU: whole-image frames cover only the tiles that touch the screen rectangle of the scene's bounds (camera rays that miss
-the bounds hit nothing, and the image was cleared).  With the rectangle on and off the bytes and the ray counts must be the
-same, for cameras that see all of the scene, a corner of it, none of it, and for cameras inside it or with parts of it
-behind them (then the frame stays whole)."""
+"""GPU: a single-launch frame visits only the 8x8 pixel blocks that can see the scene: those under the screen rectangles of the
+boxes of a cut through the hierarchy (camera rays through the others miss every box, and the image was cleared).  With the
+list on and off the bytes and the ray counts must be the same -- for cameras that see all of the scene, a corner of it, none
+of it, for cameras inside it or with parts of it behind them (then every block is visited), for a rank's packed tiles and
+for a scene that came back from its cache file."""
 import numpy as np
 import pytest
 
@@ -25,14 +26,14 @@ CAMERAS = {
 
 @pytest.mark.parametrize("size", [(640, 400), (333, 211)])
 @pytest.mark.parametrize("name", sorted(CAMERAS))
-def test_frame_with_and_without_the_screen_rectangle(name, size, monkeypatch):
+def test_frame_with_and_without_the_block_list(name, size, monkeypatch):
     from raytracer_amd.device import DeviceScene
     w, h = size
     fs = FlatScene.from_text("size %d %d\nmaxdepth 3\n%s\n%s" % (w, h, CAMERAS[name], OBJ))
     with DeviceScene(fs, 0) as s:
-        monkeypatch.setenv("MIRT_SCREEN_RECT", "0")
+        monkeypatch.setenv("MIRT_BLOCK_LIST", "0")
         want, wst = s.render()
-        monkeypatch.setenv("MIRT_SCREEN_RECT", "1")
+        monkeypatch.setenv("MIRT_BLOCK_LIST", "1")
         for _ in range(2):
             img = np.full((h, w, 3), 0x77, np.uint8)
             _, st = s.render(out=img)
@@ -53,3 +54,30 @@ def test_against_the_oracle_with_the_scene_in_a_corner():
         img, st = s.render()
     assert np.array_equal(img, want)
     assert [st[k] for k in ("primary_rays", "shadow_rays", "reflection_rays")] == [wst[k] for k in ("primary_rays", "shadow_rays", "reflection_rays")]
+
+
+@pytest.mark.parametrize("tiles", [dict(tile_w=64, tile_h=16, first_tile=1, tile_stride=3), dict(tile_w=32, tile_h=32, first_tile=0, tile_stride=2)])
+def test_a_ranks_packed_tiles(tiles, flat_scenes, monkeypatch):
+    from raytracer_amd.device import DeviceScene
+    with DeviceScene(flat_scenes("scene7"), 0) as s:
+        for w, h in ((1000, 700), (333, 211)):
+            monkeypatch.setenv("MIRT_BLOCK_LIST", "0")
+            want, wst = s.render(w, h, **tiles)
+            monkeypatch.setenv("MIRT_BLOCK_LIST", "1")
+            got, st = s.render(w, h, **tiles)
+            assert want.any() and np.array_equal(got, want)
+            assert {**st, "device_ms": 0} == {**wst, "device_ms": 0}
+
+
+def test_scene_from_its_cache_file(flat_scenes, goldens, tmp_path, monkeypatch):
+    from raytracer_amd.device import DeviceScene
+    path = str(tmp_path / "scene7.mirt")
+    with DeviceScene(flat_scenes("scene7"), 0) as s:
+        s.save(path)
+        want, wst = s.render(1280, 720)
+    cached, _ = DeviceScene.load(path, 0)
+    with cached as s:
+        got, st = s.render(1280, 720)
+        assert np.array_equal(got, want) and {**st, "device_ms": 0} == {**wst, "device_ms": 0}
+        monkeypatch.setenv("MIRT_BLOCK_LIST", "0")
+        assert np.array_equal(s.render(1280, 720)[0], want)
