@@ -12,8 +12,9 @@ byte for byte with a frame rendered alone, and the synchronous host call's image
 Rank 0 prints ONE JSON line.  Rays are counted the way the reference's control flow spawns them
 (RayTracer/main.cpp:176-223): primary = pixels, shadow = lights x hits at every depth, reflection = hits at depth < maxdepth.
 
-Beside `value` the line carries `frame_alone_ms` (one frame, nothing else on the GPU), `sync_host_ms` (mirt_render: the
-call that replaces main.cpp:137-163, host buffer out), `roofline` (see roofline()) and `cpu_baseline` (rank 0, N = 1: the
+Beside `value` the line carries `steady_state` (the same pipeline over 80 frames, outside the timed region),
+`shader_clock_hz` (measured beside those frames), `frame_alone_ms` (one frame, nothing else on the GPU), `sync_host_ms`
+(mirt_render: the call that replaces main.cpp:137-163, host buffer out), `roofline` (see roofline()) and `cpu_baseline` (rank 0, N = 1: the
 reference's own compiled classes, oracle/_ref, kind "reference" -- or the C restatement, kind "port" -- on a bounded row
 sample of the same image, one thread, plus what 16 processes of it reach together).
 """

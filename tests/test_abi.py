@@ -18,9 +18,14 @@ def test_library_exports_every_declared_symbol():
     assert declared == bound | node, (declared ^ (bound | node))
     for name in bound:
         assert getattr(lib, name) is not None
-    nlib = _capi.load_node_library()
-    for name in node:
-        assert getattr(nlib, name) is not None
+    # libmirt_node.so brings the system's librccl with it; a process that also imports torch (which ships an RCCL of its own)
+    # must not hold both, so the node library is looked at in a process of its own
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\nfrom raytracer_amd import _capi\nlib = _capi.load_node_library()\n"
+            "missing = [n for n, _, _ in _capi.NODE_SYMBOLS if getattr(lib, n, None) is None]\nprint('missing', missing)\nsys.exit(1 if missing else 0)\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
 
 
 def test_struct_sizes_match_header_layout():
