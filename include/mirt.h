@@ -129,7 +129,9 @@ typedef struct mirt_scene_desc {
  *   EXACT:   primitives are enumerated through the library's own hierarchy over the primitives; a candidate counts only
  *            if one of the Partition leaves that hold it passes AABB::intersect (AABB.cpp:53-72, evaluated exactly).
  *            Same result as Partition::intersect (Partition.cpp:35-53) including its tie-breaks.
- *   FAST:    as EXACT without the leaf-box check: differs only for a hit the reference's tree would not have reached, and
+ *   FAST:    as EXACT without the leaf-box check: differs only for a hit the reference's tree would not have reached (the
+ *            bounds the reference computes for a rotated or off-centre scaled sphere do not contain it, Sphere.cpp:13-41: the
+ *            reference and EXACT draw such a sphere clipped by those bounds, FAST draws all of it), and
  *            where two primitives are hit at the same distance (it takes the lower primitive number; the reference the one
  *            its tree visits first); also ends a path at a material whose specular weight is zero instead of tracing the
  *            weightless reflection.  The triangle test is still the reference's (Triangle.cpp:147-171: plane hit and three

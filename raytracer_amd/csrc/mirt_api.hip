@@ -697,6 +697,8 @@ int upload(DevBuf& b, const void* src, size_t bytes) {
 	return MIRT_OK;
 }
 
+int refwalk_ok(const mirt_scene* s, uint32_t mode);
+
 int check_params(const mirt_scene* s, const mirt_render_params* p, uint32_t& tileW, uint32_t& tileH) {
 	if (!s) return fail(MIRT_E_INVALID, "scene handle is NULL");
 	if (!p) return fail(MIRT_E_INVALID, "render params are NULL");
@@ -704,6 +706,7 @@ int check_params(const mirt_scene* s, const mirt_render_params* p, uint32_t& til
 	if (p->width == 0 || p->height == 0 || p->width > 65536 || p->height > 65536) return fail(MIRT_E_INVALID, "image size %ux%u not supported", p->width, p->height);
 	if (p->debug_mode > MIRT_DEBUG_NONE) return fail(MIRT_E_INVALID, "debug_mode %u unknown", p->debug_mode);
 	if (p->trace_mode > MIRT_TRACE_REFWALK) return fail(MIRT_E_INVALID, "trace_mode %u unknown", p->trace_mode);
+	if (int e = refwalk_ok(s, p->trace_mode)) return e;
 	tileW = p->tile_w ? p->tile_w : 32;
 	tileH = p->tile_h ? p->tile_h : 32;
 	if ((tileW & 7) || (tileH & 7) || tileW > 1024 || tileH > 1024) return fail(MIRT_E_INVALID, "tile size %ux%u must be multiples of 8, at most 1024", tileW, tileH);
@@ -843,6 +846,12 @@ struct Uploader {
 
 // a tree whose boxes are not nested is walked as it is, whatever mode was asked for
 int effective_mode(const mirt_scene* s, uint32_t mode) { return s->nested ? (int)mode : MODE_REFWALK; }
+// MODE_REFWALK keeps one stack entry per level of the packed reference tree in private memory (STACK_MAX of them)
+int refwalk_ok(const mirt_scene* s, uint32_t mode) {
+	if (effective_mode(s, mode) == MODE_REFWALK && s->wideDepth + 2 > STACK_MAX)
+		return fail(MIRT_E_INVALID, "MIRT_TRACE_REFWALK: Partition tree depth %u exceeds the traversal stack (%d); use MIRT_TRACE_EXACT", s->wideDepth, STACK_MAX);
+	return MIRT_OK;
+}
 
 // event after launch i (event 0 precedes the first launch); only when profiling is on
 void mark(mirt_scene* s, FrameCtx* c, hipStream_t st, int kind) {
@@ -1687,7 +1696,9 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		if (Packer::isLeaf(rn)) ds.rootRef = REF_LEAF | pk.leafPos[r];
 		else {
 			ds.rootRef = 0;
-			if (!pk.run(r, refWide, refDepth) || refDepth + 2 > STACK_MAX)
+			// A tree deeper than MIRT_TRACE_REFWALK's private stack is still a scene: the other modes never walk it (renders that
+			// ask for REFWALK are refused, see refwalk_ok).  Only a tree whose boxes are not nested has no other mode.
+			if (!pk.run(r, refWide, refDepth) || (refDepth + 2 > STACK_MAX && !s->nested))
 				return bail(fail(MIRT_E_INVALID, "Partition tree depth %u exceeds the traversal stack (%d)", refDepth, STACK_MAX));
 		}
 	}
@@ -2375,6 +2386,7 @@ int mirt_assemble_tiles(int device, const mirt_render_params* p, uint32_t n_rank
 int mirt_trace_rays(mirt_scene* s, uint32_t trace_mode, uint64_t n, const float* origins, const float* dirs, int32_t* prim_id_out, float* dist_out, float* normal_out) {
 	if (!s) return fail(MIRT_E_INVALID, "scene handle is NULL");
 	if (trace_mode > MIRT_TRACE_REFWALK) return fail(MIRT_E_INVALID, "trace_mode %u unknown", trace_mode);
+	if (int e = refwalk_ok(s, trace_mode)) return e;
 	if (n == 0) return MIRT_OK;
 	if (!origins || !dirs || !prim_id_out || !dist_out) return fail(MIRT_E_INVALID, "NULL ray or result array");
 	HIPCHK(hipSetDevice(s->device));
@@ -2427,6 +2439,7 @@ int mirt_test_powf(int device, uint64_t n, const float* x, const float* y, float
 int mirt_trace_primary_ids(mirt_scene* s, uint32_t trace_mode, uint32_t width, uint32_t height, int32_t* prim_id_out, float* dist_out) {
 	if (!s) return fail(MIRT_E_INVALID, "scene handle is NULL");
 	if (trace_mode > MIRT_TRACE_REFWALK) return fail(MIRT_E_INVALID, "trace_mode %u unknown", trace_mode);
+	if (int e = refwalk_ok(s, trace_mode)) return e;
 	if (!prim_id_out || !dist_out || width == 0 || height == 0) return fail(MIRT_E_INVALID, "NULL result array or empty image");
 	HIPCHK(hipSetDevice(s->device));
 	const uint64_t n = (uint64_t)width * height;

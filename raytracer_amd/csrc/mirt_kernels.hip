@@ -282,19 +282,29 @@ __device__ __forceinline__ float sphere_hit(const RayCtx& r, const float4* __res
 // the triangle (Triangle::isInside is an overlap test, Triangle.cpp:58-95), so every candidate at a distance <= best is
 // still visited and the result equals the reference's exhaustive walk (Partition.cpp:42-52).  Sphere::isInside
 // (Sphere.cpp:43-57) gives no such guarantee -- a transformed sphere can be hit outside every leaf that holds it -- so
-// with spheres in the scene (S.refCull == 0) nothing is skipped.  Stack in private memory: this mode is the fallback and
-// the cross-check, not the fast path.
+// with spheres in the scene (S.refCull == 0) nothing is skipped.
+// One thing the skipping does change: which of two primitives hit at the SAME distance the reference returns is decided
+// by the first place either of them occupies among all the leaves the ray's boxes lead to (Partition.cpp:47, Partition.h:33)
+// -- and a triangle also sits in leaves far behind the hit, which a bounded walk never sees.  Both rivals are always met
+// (each lies in a leaf around the hit point), so the tie itself is noticed, and such a ray is walked a second time without
+// the bound.  Stack in private memory: this mode is the fallback and the cross-check, not the fast path.
 template <bool ANY>
 __device__ __noinline__ bool traverse_ref(const DScene& S, const RayCtx& r, float limit, Hit& best) {
+	float tn;
+	const f3 e = box_dir(r);
+	if (S.rootRef == REF_NONE || !box_hit<MODE_EXACT>(r, e, F3(S.rootMin), F3(S.rootMax), tn)) { // Partition.cpp:36 on the root
+		best.dist = __builtin_inff();
+		best.ref = REF_NONE;
+		return false;
+	}
+	uint32_t stkRef[STACK_MAX];
+	float stkT[STACK_MAX];
+	bool cull = S.refCull != 0, tie = false;
+ again:
 	best.dist = __builtin_inff();
 	best.ref = REF_NONE;
 	best.pos = 0xffffffffu;
-	float tcull = (ANY && S.refCull) ? (limit * r.invLen * 1.0001f + 1e-5f) : __builtin_inff();
-	float tn;
-	const f3 e = box_dir(r);
-	if (S.rootRef == REF_NONE || !box_hit<MODE_EXACT>(r, e, F3(S.rootMin), F3(S.rootMax), tn)) return false; // Partition.cpp:36 on the root
-	uint32_t stkRef[STACK_MAX];
-	float stkT[STACK_MAX];
+	float tcull = (ANY && cull) ? (limit * r.invLen * 1.0001f + 1e-5f) : __builtin_inff();
 	int sp = 0;
 	uint32_t cur = S.rootRef;
 	for (;;) {
@@ -334,18 +344,24 @@ __device__ __noinline__ bool traverse_ref(const DScene& S, const RayCtx& r, floa
 					if (ANY) {
 						if (dist < limit) { best.dist = dist; best.ref = pr; best.pos = pos; return true; }
 					}
-					else if (dist < best.dist || (dist == best.dist && pos < best.pos)) { // Partition.h:33, Partition.cpp:47
-						best.dist = dist;
-						best.ref = pr;
-						best.pos = pos;
-						if (S.refCull) tcull = dist * r.invLen * 1.0001f + 1e-5f;
+					else {
+						if (dist == best.dist && pr != best.ref) tie = true;
+						if (dist < best.dist || (dist == best.dist && pos < best.pos)) { // Partition.h:33, Partition.cpp:47
+							best.dist = dist;
+							best.ref = pr;
+							best.pos = pos;
+							if (cull) tcull = dist * r.invLen * 1.0001f + 1e-5f;
+						}
 					}
 				}
 			}
 		}
 		// pop the next subtree that can still matter
 		for (;;) {
-			if (sp == 0) return best.ref != REF_NONE;
+			if (sp == 0) {
+				if (!ANY && cull && tie) { cull = false; goto again; }
+				return best.ref != REF_NONE;
+			}
 			--sp;
 			cur = stkRef[sp];
 			if (!(stkT[sp] > tcull)) break;
@@ -870,7 +886,7 @@ __device__ __forceinline__ void walk_wave_share(const DScene& S, Walker<MODE, OV
 		const bool wantNode = c >= 0, wantLeaf = c < -1;
 		const uint32_t nNode = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(wantNode)), nLeaf = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(wantLeaf));
 		if (nNode + nLeaf == 0u) break;
-#if MIRT_TIMELINE
+#if MIRT_TIMELINE >= 2 // (atomics on one word each per wave iteration: this build's times are many times the library's)
 		{
 			// idle lanes of this iteration by kind: holding a hit of their own / owners that gave work away / free to help
 			const uint32_t nHold = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(c == -1 && (grp & 63u) == lane && w.best.ref != REF_NONE));
@@ -885,7 +901,7 @@ __device__ __forceinline__ void walk_wave_share(const DScene& S, Walker<MODE, OV
 			const unsigned long long freeM = __builtin_amdgcn_ballot_w64(free), giveM = __builtin_amdgcn_ballot_w64(gives);
 			const uint32_t nF = (uint32_t)__popcll(freeM), nG = (uint32_t)__popcll(giveM);
 			if (nF >= MIRT_SHARE_MIN_FREE / 2 && nG) {
-#if MIRT_TIMELINE
+#if MIRT_TIMELINE >= 2 // (atomics on one word each per wave iteration: this build's times are many times the library's)
 				{
 					const uint32_t nHold = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(c == -1 && w.best.ref != REF_NONE && (grp & 63u) == lane && !(grp & 64u)));
 					if (lane == 0) { atomicAdd(S.dbg + 12, 1ull); atomicAdd(S.dbg + 13, (unsigned long long)(nF < nG ? nF : nG)); atomicAdd(S.dbg + 14, (unsigned long long)nHold); atomicAdd(S.dbg + 15, (unsigned long long)nF); }

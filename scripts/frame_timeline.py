@@ -2,8 +2,8 @@
 """Diagnostic (a -DMIRT_TIMELINE=1 build of mirt_api.hip as exp/libmirt_timeline.so): where the time of ONE k_frame launch goes.
 Prints, in microseconds from the first wave's start: when the pixel slots ran out (first / last wave to notice), when the last
 wave ended, the mean wave lifetime and the mean time a wave spent after the slots had run out, rounds and lane use, the idle
-lanes by kind and the hand-overs of stack entries between lanes (the counters of the last line are atomics on one word each, and so
-many of them that this build's times are several times the library's: read its last line for the counts only)."""
+lanes by kind and the hand-overs of stack entries between lanes (the counters of the last line exist in a -DMIRT_TIMELINE=2 build
+only: atomics on one word each, so many that such a build's times are a hundred times the library's; =1 keeps the library's times)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

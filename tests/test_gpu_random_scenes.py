@@ -1,0 +1,66 @@
+"""GPU: seeded random scenes (tests/random_scenes.py: nested transforms, both kinds of light, every material command, and
+constructions full of equal-distance ties) -- scene text -> the library's loader -> device, byte for byte against the C
+restatement on the same flattened scene, which tests/test_random_scenes.py holds to the reference's own build on the same
+seeds.  Every trace mode that promises the reference's bytes, the small-stack build, and a frame five times the size (more
+waves, shared walks, several batches per wave)."""
+import os
+
+import numpy as np
+import pytest
+
+from random_scenes import random_scene_text
+from raytracer_amd import _capi
+from raytracer_amd.scene import FlatScene
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("primary_rays", "shadow_rays", "reflection_rays")
+
+
+# (MIRT_RANDOM_SEEDS=first:end runs another range of seeds, for a longer hunt than the suite's)
+# 179, 401, 455, 701: two triangles at the same distance, one of which also sits in a leaf far behind the hit (the walk of
+# the reference's tree has to notice the tie and drop its distance bound); 244: a Partition tree 304 levels deep
+SEEDS = (range(*(int(x) for x in os.environ["MIRT_RANDOM_SEEDS"].split(":"))) if os.environ.get("MIRT_RANDOM_SEEDS")
+         else list(range(48)) + [179, 244, 401, 455, 701])
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_scene_matches_the_oracle(seed):
+    from oracle.bind import CPort
+    from raytracer_amd.device import DeviceScene, MirtError
+    fs = FlatScene.from_text(random_scene_text(seed))
+    port = CPort(fs)
+    want, wst = port.render()
+    W, H = fs.width * 5, fs.height * 5
+    big, bst = port.render(W, H)
+    libs = [None]
+    if seed % 3 == 0:
+        libs.append(_capi.load_library(os.path.join(os.path.dirname(_capi.__file__), "libmirt_smallstack.so")))
+    for lib in libs:
+        with DeviceScene(fs, 0, lib=lib) as s:
+            for mode in (_capi.TRACE_EXACT, _capi.TRACE_REFWALK):
+                if mode == _capi.TRACE_REFWALK and s.query()["tree_wide_depth"] + 2 > 96:
+                    # the walk of the reference's tree keeps a private stack of 96 levels; such a tree is left to the other modes
+                    with pytest.raises(MirtError, match="REFWALK"):
+                        s.render(trace_mode=mode)
+                    continue
+                img, st = s.render(trace_mode=mode)
+                assert np.array_equal(img, want), (seed, mode, lib is not None)
+                assert [st[k] for k in KEYS] == [wst[k] for k in KEYS]
+            img, st = s.render(W, H)
+            assert np.array_equal(img, big), (seed, "x5", lib is not None)
+            assert [st[k] for k in KEYS] == [bst[k] for k in KEYS]
+            # the ids and distances of the camera rays, bit for bit
+            o, d = port.primary_rays(fs.width, fs.height)
+            ids, dist, _, _ = port.trace(o, d)
+            gi, gd = s.trace_primary_ids()
+            assert np.array_equal(gi, ids) and np.array_equal(gd.view(np.uint32), dist.view(np.uint32))
+            # MIRT_TRACE_FAST drops the leaf-box check: it sees every hit the reference sees, nothing nearer is lost, and more
+            # only where the reference's tree cannot reach a primitive (the bounds the reference gives a rotated or scaled
+            # sphere do not contain it, Sphere.cpp:13-41: the reference draws such a sphere clipped, FAST draws all of it)
+            fi, fd = s.trace_primary_ids(trace_mode=_capi.TRACE_FAST)
+            assert not np.any((ids >= 0) & (fi < 0))
+            both = (ids >= 0) & (fi >= 0)
+            assert np.all(fd[both] <= dist[both])
+            if fs.n_prims == len(fs.tri_prim):
+                assert np.array_equal(fi >= 0, ids >= 0)
