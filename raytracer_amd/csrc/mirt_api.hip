@@ -1685,6 +1685,19 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		});
 	}
 	up.push(s->leafs, refStream.p, refStream.n * 4);
+	// DScene::nanHit: the first sphere of the last leaf (flat nodes are in pre-order: left to right) that holds one
+	ds.nanHit = REF_NONE;
+	if (d->n_spheres) {
+		for (uint32_t i = d->n_nodes; i-- > 0 && ds.nanHit == REF_NONE;) {
+			const mirt_node& n = d->nodes[i];
+			if (!(n.b & MIRT_LEAF_FLAG)) continue;
+			const uint32_t cnt = n.b & ~MIRT_LEAF_FLAG;
+			for (uint32_t k = 0; k < cnt; ++k) {
+				const int64_t sl = primSlot[d->leaf_prims[n.a + k]];
+				if (sl < 0 && sl != INT64_MIN) { ds.nanHit = PRIM_SPHERE | sphNew[(uint32_t)(-1 - sl)]; break; }
+			}
+		}
+	}
 	ds.rootRef = REF_NONE;
 	ds.refCull = d->n_spheres == 0 ? 1u : 0u;
 	for (int k = 0; k < 3; ++k) { ds.rootMin[k] = 0.0f; ds.rootMax[k] = -1.0f; }
@@ -1749,6 +1762,13 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		for (uint32_t i = 0; i < d->n_lights && ok; ++i) for (int k = 0; k < 3; ++k) ok = ok && fabsf(d->lights[i].color[k]) <= 1e15f;
 		if (const char* env = getenv("MIRT_SHADOW_CULL")) ok = ok && atoi(env) != 0;
 		ds.shadowCull = ok ? 1u : 0u;
+	}
+	{
+		// cull_bound(): where a ray of this scene can start -- at the camera, or on a primitive
+		float far = (fabsf(ds.cam.eye[0]) + fabsf(ds.cam.eye[1])) + fabsf(ds.cam.eye[2]), box = 0.0f;
+		for (int k = 0; k < 3; ++k) box += fmaxf(fmaxf(fabsf(ds.bvhMin[k]), fabsf(ds.bvhMax[k])), fmaxf(fabsf(ds.rootMin[k]), fabsf(ds.rootMax[k])));
+		far = fmaxf(far, box);
+		ds.cullSlack = std::isfinite(far) ? 1e-5f + far * 0x1p-17f * 1.01f : __builtin_inff(); // (camera rays: |alpha u + beta v - w| >= 1, Camera.cpp:21-23)
 	}
 	s->nLights = d->n_lights;
 	s->maxDepth = d->max_depth;
@@ -1819,7 +1839,7 @@ void mirt_scene_destroy(mirt_scene* s) {
 // (pointers meaningless), SceneMeta, then for each of the eleven device arrays a 64-bit byte count and the bytes.
 namespace {
 const char SCENE_MAGIC[8] = {'M', 'I', 'R', 'T', 'S', 'C', 'N', '1'};
-const uint32_t SCENE_VERSION = 3;
+const uint32_t SCENE_VERSION = 4;
 struct SceneHeader {
 	char magic[8];
 	uint32_t version, dsceneBytes, metaBytes, pad;
@@ -2400,7 +2420,19 @@ int mirt_trace_rays(mirt_scene* s, uint32_t trace_mode, uint64_t n, const float*
 	if (!e) {
 		const int grid = (int)((n + BLOCK - 1) / BLOCK < (uint64_t)s->numCUs * GRID_BLOCKS_PER_CU ? (n + BLOCK - 1) / BLOCK : (uint64_t)s->numCUs * GRID_BLOCKS_PER_CU);
 		const int mode = effective_mode(s, trace_mode);
-#define LAUNCH_LIST(M, O) hipLaunchKernelGGL((k_trace_list<M, O>), dim3(grid), dim3(BLOCK), 0, s->stream, s->ds, (uint32_t*)s->hookOvf.p, s->ovfStride, n, (const float*)o.p, (const float*)d.p, (int32_t*)id.p, (float*)dist.p, (float*)nrm.p)
+		// (cull_bound(): these rays start wherever the caller says)
+		DScene dsl = s->ds;
+		{
+			float far = 0.0f, shortest = 1.0f;
+			for (uint64_t i = 0; i < n; ++i) {
+				far = fmaxf(far, (fabsf(origins[i * 3]) + fabsf(origins[i * 3 + 1])) + fabsf(origins[i * 3 + 2]));
+				const float len = sqrtf(dirs[i * 3] * dirs[i * 3] + dirs[i * 3 + 1] * dirs[i * 3 + 1] + dirs[i * 3 + 2] * dirs[i * 3 + 2]);
+				if (len < shortest) shortest = len; // (a NaN direction never walks)
+			}
+			const float c = 1e-5f + far * 0x1p-17f * 1.01f / shortest;
+			dsl.cullSlack = std::isfinite(c) ? fmaxf(dsl.cullSlack, c) : __builtin_inff();
+		}
+#define LAUNCH_LIST(M, O) hipLaunchKernelGGL((k_trace_list<M, O>), dim3(grid), dim3(BLOCK), 0, s->stream, dsl, (uint32_t*)s->hookOvf.p, s->ovfStride, n, (const float*)o.p, (const float*)d.p, (int32_t*)id.p, (float*)dist.p, (float*)nrm.p)
 		if (mode == MODE_REFWALK) LAUNCH_LIST(MODE_REFWALK, false);
 		else if (mode == MODE_FAST) { if (s->deepBvh) LAUNCH_LIST(MODE_FAST, true); else LAUNCH_LIST(MODE_FAST, false); }
 		else { if (s->deepBvh) LAUNCH_LIST(MODE_EXACT, true); else LAUNCH_LIST(MODE_EXACT, false); }

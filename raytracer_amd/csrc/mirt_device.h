@@ -67,7 +67,12 @@ struct DScene {
 	// (2) membership lists
 	const float4* memb;
 	unsigned long long* dbg; // diagnostic event counters (MIRT_STATS builds)
-	uint32_t pad0;
+	// What a ray whose direction is NaN "hits" in the reference (a light exactly at the hit point: normalize(0), main.cpp:222):
+	// every box passes (AABB.cpp:60-72: no comparison with a NaN is true), no triangle does (Triangle.cpp:163-166), every
+	// sphere returns a NaN distance, which counts as valid (SceneObjects.hpp:35-37), and between two NaN answers a node takes
+	// the right one (Partition.cpp:47), a leaf the first (Partition.h:33): the first sphere of the last leaf that holds one.
+	// REF_NONE in a scene without spheres.
+	uint32_t nanHit;
 	uint32_t bvhRoot;
 	float bvhMin[3], bvhMax[3];
 	// (3) reference tree
@@ -82,6 +87,7 @@ struct DScene {
 	uint32_t nLights;
 	int32_t maxDepth;
 	float atten[3];
+	float cullSlack;     // see cull_bound()
 	uint32_t shadowCull; // 1: shadow queries whose light term is provably multiplied by zero may be skipped (host-checked premises)
 	DCamera cam;
 };

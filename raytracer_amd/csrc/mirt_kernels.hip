@@ -100,6 +100,17 @@ __device__ __forceinline__ RayCtx make_ray(f3 o, f3 d) {
 	return r;
 }
 
+// Ray parameter beyond which nothing can come closer than `dist`.  A hit's distance is |o - (o + t d)| as the reference
+// rounds it (Triangle.cpp:158,167; Sphere.cpp:81-82): off t |d| by a few ulps of the COORDINATES, not of the distance -- far
+// from the origin that is more than any relative slack on dist -- hence S.cullSlack: 1e-5 plus 2^-17 of the largest
+// |x| + |y| + |z| a ray of this scene can start from (the camera, the corners of the scene's bounds), in units of the ray
+// parameter of the shortest direction vector in use (camera rays are at least 1 long, all others normalised; the ray-batch
+// entry points look at the rays they are given).
+__device__ __forceinline__ float cull_bound(const DScene& S, const RayCtx& r, float dist) {
+	return dist * r.invLen * 1.0001f + S.cullSlack;
+}
+__device__ __forceinline__ bool has_nan(f3 d) { return d.x != d.x || d.y != d.y || d.z != d.z; }
+
 // The direction with AABB.cpp:53-58's substitution: |d| < 1e-5 -> +1e-5.  Not kept in RayCtx: only the reference's own
 // box test needs it, and three registers held through the whole walk cost more than recomputing it there.
 __device__ __forceinline__ f3 box_dir(const RayCtx& r) {
@@ -304,7 +315,7 @@ __device__ __noinline__ bool traverse_ref(const DScene& S, const RayCtx& r, floa
 	best.dist = __builtin_inff();
 	best.ref = REF_NONE;
 	best.pos = 0xffffffffu;
-	float tcull = (ANY && cull) ? (limit * r.invLen * 1.0001f + 1e-5f) : __builtin_inff();
+	float tcull = (ANY && cull) ? cull_bound(S, r, limit) : __builtin_inff();
 	int sp = 0;
 	uint32_t cur = S.rootRef;
 	for (;;) {
@@ -350,7 +361,7 @@ __device__ __noinline__ bool traverse_ref(const DScene& S, const RayCtx& r, floa
 							best.dist = dist;
 							best.ref = pr;
 							best.pos = pos;
-							if (cull) tcull = dist * r.invLen * 1.0001f + 1e-5f;
+							if (cull) tcull = cull_bound(S, r, dist);
 						}
 					}
 				}
@@ -499,8 +510,14 @@ struct Walker {
 		best.dist = __builtin_inff();
 		best.ref = REF_NONE;
 		best.pos = 0xffffffffu;
-		tcull = lim >= 0.0f ? (lim * r.invLen * 1.0001f + 1e-5f) : __builtin_inff();
+		tcull = lim >= 0.0f ? cull_bound(S, r, lim) : __builtin_inff();
 		sp = 0;
+		if (has_nan(d)) { // see DScene::nanHit
+			best.ref = S.nanHit;
+			best.dist = __builtin_nanf("");
+			cur = BVH_DONE;
+			return false;
+		}
 		cur = S.bvhRoot;
 		float tn;
 		const float4 lo = make_float4(S.bvhMin[0], S.bvhMin[1], S.bvhMin[2], 0.0f), hi = make_float4(S.bvhMax[0], S.bvhMax[1], S.bvhMax[2], 0.0f);
@@ -637,7 +654,7 @@ struct Walker {
 			best.dist = dist;
 			best.ref = ref;
 			if (STRICT) best.pos = pos;
-			tcull = dist * r.invLen * 1.0001f + 1e-5f;
+			tcull = cull_bound(S, r, dist);
 		}
 		return false;
 	}
@@ -672,7 +689,7 @@ struct Walker {
 	__device__ __forceinline__ bool verify(const DScene& S) const {
 		if (MODE != MODE_EXACT) return true;
 		if (needStrict) return false;
-		if (best.ref == REF_NONE) return true;
+		if (best.ref == REF_NONE || best.dist != best.dist) return true; // (a NaN distance: the answer to a NaN direction, see start())
 		STAT_WAVE(S, 4);
 		STAT_LANE(S, 5);
 		const uint4 info = (best.ref & PRIM_SPHERE) ? S.sphInfo[best.ref & ~PRIM_SPHERE] : S.triInfo[best.ref];
@@ -684,6 +701,12 @@ struct Walker {
 template <int MODE, bool OVF, class STK>
 __device__ __forceinline__ void trace_whole(const DScene& S, f3 o, f3 d, float limit, Hit& best, STK& stk) {
 	if (MODE == MODE_REFWALK) {
+		if (has_nan(d)) { // see DScene::nanHit
+			best.ref = S.nanHit;
+			best.dist = __builtin_nanf("");
+			best.pos = 0;
+			return;
+		}
 		const RayCtx r = make_ray(o, d);
 		if (limit >= 0.0f) traverse_ref<true>(S, r, limit, best);
 		else traverse_ref<false>(S, r, limit, best);

@@ -132,3 +132,148 @@ def random_scene_text(seed):
     out += verts
     out += body
     return "\n".join(out) + "\n"
+
+
+def hard_scene_text(seed):
+    """The unkind cases: axis-parallel camera rays over axis-aligned geometry (direction components that are exactly zero or
+    below the 1e-5 that AABB.cpp:53-58 replaces), coordinates far from the origin, slivers and specks beside huge triangles, the
+    camera inside a sphere or between two mirrors, lights on surfaces and inside objects, one-pixel-wide images, meshes of a few
+    thousand triangles with shared vertices (deeper trees, long walks)."""
+    rng = np.random.default_rng(100000 + seed)
+    kind = seed % 6
+    out = []
+    verts = []
+    body = []
+
+    def vertex(p):
+        verts.append("vertex %s" % _vec(p))
+        return len(verts) - 1
+
+    def material(spec=None):
+        body.append("ambient %s" % _vec(rng.uniform(0, 0.2, 3)))
+        body.append("diffuse %s" % _vec(rng.uniform(0.1, 1, 3)))
+        body.append("specular %s" % _vec(rng.uniform(0.2, 0.95, 3) if spec is None else spec))
+        body.append("shininess %s" % _f(rng.choice([0.5, 2, 30, 128])))
+
+    def quad(p0, e1, e2):
+        a, b, c, d = vertex(p0), vertex(p0 + e1), vertex(p0 + e1 + e2), vertex(p0 + e2)
+        body.append("tri %d %d %d" % (a, b, c))
+        body.append("tri %d %d %d" % (a, c, d))
+
+    def mesh(n, m, f, flip=False):
+        """an n x m grid of vertices f(u, v), two triangles per cell, vertices shared"""
+        idx = [[vertex(f(i / (n - 1.0), j / (m - 1.0))) for j in range(m)] for i in range(n)]
+        for i in range(n - 1):
+            for j in range(m - 1):
+                a, b, c, d = idx[i][j], idx[i + 1][j], idx[i + 1][j + 1], idx[i][j + 1]
+                body.append("tri %d %d %d" % ((a, c, b) if flip else (a, b, c)))
+                body.append("tri %d %d %d" % ((a, d, c) if flip else (a, c, d)))
+
+    if kind == 0:
+        # camera on an axis, looking along it, at axis-aligned quads: whole rows and columns of rays have a zero component
+        w, h = int(rng.integers(8, 40)) * 2 + 1, int(rng.integers(8, 30)) * 2 + 1
+        out += ["size %d %d" % (w, h), "maxdepth %d" % int(rng.integers(0, 5)), "camera 0 0 %s 0 0 0 0 1 0 %s" % (_f(rng.integers(3, 8)), _f(rng.choice([30, 45, 60, 90])))]
+        out.append("point 0 0 %s 1 1 1" % _f(rng.integers(1, 4)))
+        out.append("directional 0 0 1 0.3 0.3 0.3")
+        out.append("directional 0 1 0 0.2 0.2 0.2")
+        material()
+        n = int(rng.integers(1, 5))
+        for i in range(-n, n):
+            for j in range(-n, n):
+                if rng.random() < 0.2:
+                    material()
+                quad(np.array([float(i), float(j), -float(rng.integers(0, 3))]), np.array([1.0, 0, 0]), np.array([0, 1.0, 0]))
+        for _ in range(int(rng.integers(0, 4))):  # walls parallel to the viewing direction
+            x = float(rng.integers(-n, n + 1))
+            quad(np.array([x, -float(n), -2.0]), np.array([0, 2.0 * n, 0]), np.array([0, 0, 3.0]))
+        body.append("sphere 0 0 0 %s" % _f(rng.choice([0.25, 0.5, 1.0])))
+    elif kind == 1:
+        # far from the origin, and very different sizes side by side
+        off = rng.choice([1e2, 1e3, 1e4]) * rng.choice([-1.0, 1.0], 3)
+        w, h = int(rng.integers(20, 90)), int(rng.integers(12, 60))
+        out += ["size %d %d" % (w, h), "maxdepth %d" % int(rng.integers(0, 6))]
+        out.append("camera %s %s 0 1 0 %s" % (_vec(off + np.array([0.3, 0.2, 6.0])), _vec(off), _f(rng.uniform(30, 60))))
+        out.append("point %s 1 1 1" % _vec(off + np.array([2.0, 4.0, 5.0])))
+        out.append("directional 0.3 0.5 1 0.4 0.4 0.4")
+        material()
+        quad(off + np.array([-50.0, -50.0, -1.0]), np.array([100.0, 0, 0]), np.array([0, 100.0, 0]))  # huge
+        for _ in range(int(rng.integers(10, 120))):
+            c = off + rng.uniform(-2, 2, 3)
+            s = rng.choice([1e-3, 1e-2, 0.1, 0.6])
+            if rng.random() < 0.3:
+                material()
+            idx = [vertex(c + rng.uniform(-s, s, 3)) for _ in range(3)]
+            body.append("tri %d %d %d" % tuple(idx))
+        for _ in range(int(rng.integers(0, 6))):  # slivers
+            c = off + rng.uniform(-2, 2, 3)
+            e = rng.uniform(-1, 1, 3)
+            a, b, cc = vertex(c), vertex(c + e), vertex(c + e * 0.5 + rng.uniform(-1e-4, 1e-4, 3))
+            body.append("tri %d %d %d" % (a, b, cc))
+        body.append("pushTransform")
+        body.append("translate %s" % _vec(off))
+        body.append("sphere 0 0 0 %s" % _f(rng.uniform(0.3, 1.0)))
+        body.append("scale 1 %s 1" % _f(rng.choice([0.05, 3.0])))
+        body.append("sphere 1.5 0 0 0.5")
+        body.append("popTransform")
+    elif kind == 2:
+        # camera inside a big sphere, mirrors and lights inside with it; a light exactly on a surface
+        w, h = int(rng.integers(20, 70)), int(rng.integers(12, 50))
+        out += ["size %d %d" % (w, h), "maxdepth %d" % int(rng.integers(2, 13))]
+        out.append("camera %s %s 0 1 0 %s" % (_vec(rng.uniform(-0.5, 0.5, 3)), _vec(rng.uniform(-1, 1, 3) + np.array([0, 0, -3.0])), _f(rng.uniform(40, 100))))
+        out.append("point %s 1 0.9 0.8" % _vec(rng.uniform(-1, 1, 3)))
+        out.append("point 0 -1 0 0.5 0.5 0.5")  # on the floor quad below
+        if rng.random() < 0.5:
+            out.append("attenuation 1 0.05 0.01")
+        material()
+        body.append("sphere 0 0 0 %s" % _f(rng.uniform(4.0, 9.0)))
+        material(spec=[0.9, 0.9, 0.9])
+        quad(np.array([-2.0, -1.0, -2.0]), np.array([4.0, 0, 0]), np.array([0, 0, 4.0]))
+        quad(np.array([-2.0, 1.0, -2.0]), np.array([0, 0, 4.0]), np.array([4.0, 0, 0]))
+        for _ in range(int(rng.integers(1, 8))):
+            material()
+            body.append("sphere %s %s" % (_vec(rng.uniform(-1.5, 1.5, 3)), _f(rng.uniform(0.1, 0.6))))
+    elif kind == 3:
+        # a few thousand triangles with shared vertices: a bumpy sheet and a tube around the viewing axis
+        w, h = int(rng.integers(40, 100)), int(rng.integers(30, 70))
+        out += ["size %d %d" % (w, h), "maxdepth %d" % int(rng.integers(1, 5))]
+        out.append("camera %s 0 0 0 0 1 0 %s" % (_vec(rng.uniform(-1, 1, 3) + np.array([0, 1.0, 7.0])), _f(rng.uniform(35, 60))))
+        for _ in range(int(rng.integers(1, 4))):
+            out.append("point %s %s" % (_vec(rng.uniform(-5, 5, 3) + np.array([0, 4, 2])), _vec(rng.uniform(0.3, 1, 3))))
+        material()
+        n = int(rng.integers(12, 40))
+        fx, fy, amp = rng.uniform(1, 6), rng.uniform(1, 6), rng.uniform(0.05, 0.5)
+        mesh(n, n, lambda u, v: np.array([-3 + 6 * u, amp * np.sin(fx * u * 6.28) * np.cos(fy * v * 6.28) - 1.0, -3 + 6 * v]))
+        material()
+        body.append("pushTransform")
+        body.append("rotate 0 1 0 %s" % _f(rng.uniform(0, 360)))
+        r0 = rng.uniform(0.3, 1.0)
+        mesh(int(rng.integers(8, 30)), int(rng.integers(8, 30)), lambda u, v: np.array([r0 * np.cos(6.283185 * u), -1.0 + 2.5 * v, r0 * np.sin(6.283185 * u)]), flip=rng.random() < 0.5)
+        body.append("popTransform")
+    elif kind == 4:
+        # images one pixel wide or high, odd fields of view, nothing or everything in view
+        w, h = (1, int(rng.integers(1, 200))) if rng.random() < 0.5 else (int(rng.integers(1, 300)), 1)
+        out += ["size %d %d" % (w, h), "maxdepth %d" % int(rng.integers(0, 4))]
+        out.append("camera 0 0 3 0 0 0 0 1 0 %s" % _f(rng.choice([1, 10, 120, 170])))
+        out.append("point 1 1 3 1 1 1")
+        material()
+        if rng.random() < 0.8:
+            quad(np.array([-1.0, -1.0, 0.0]), np.array([2.0, 0, 0]), np.array([0, 2.0, 0]))
+        if rng.random() < 0.5:
+            body.append("sphere 0 0 0.5 0.4")
+    else:
+        # many lights, some inside objects; primitives that pass through one another
+        w, h = int(rng.integers(20, 80)), int(rng.integers(12, 60))
+        out += ["size %d %d" % (w, h), "maxdepth %d" % int(rng.integers(0, 6))]
+        out.append("camera %s 0 0 0 0 1 0 %s" % (_vec(rng.uniform(-2, 2, 3) + np.array([0, 0, 6.0])), _f(rng.uniform(30, 60))))
+        for _ in range(int(rng.integers(5, 20))):
+            if rng.random() < 0.7:
+                out.append("point %s %s" % (_vec(rng.uniform(-2, 2, 3)), _vec(rng.uniform(0.05, 0.3, 3))))
+            else:
+                out.append("directional %s %s" % (_vec(rng.choice([-1.0, 0.0, 1.0], 3) + np.array([0, 0, 1e-6])), _vec(rng.uniform(0.05, 0.2, 3))))
+        for _ in range(int(rng.integers(3, 12))):
+            material()
+            c = rng.uniform(-1.5, 1.5, 3)
+            body.append("sphere %s %s" % (_vec(c), _f(rng.uniform(0.3, 1.2))))
+            quad(c + np.array([-1.0, -1.0, 0.0]), np.array([2.0, 0, 0]), np.array([0, 2.0, 0]))  # through the sphere's centre
+    out.append("maxverts %d" % max(1, len(verts)))
+    return "\n".join(out + verts + body) + "\n"

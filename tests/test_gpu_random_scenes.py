@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from random_scenes import random_scene_text
+from random_scenes import hard_scene_text, random_scene_text
 from raytracer_amd import _capi
 from raytracer_amd.scene import FlatScene
 
@@ -24,14 +24,30 @@ SEEDS = (range(*(int(x) for x in os.environ["MIRT_RANDOM_SEEDS"].split(":"))) if
          else list(range(48)) + [179, 244, 401, 455, 701])
 
 
+# 138, 192: a point light exactly at a hit point -- the shadow ray's direction is normalize(0) = NaN, which in the reference
+# passes every box, no triangle, and every sphere (DScene::nanHit); 433, 559, 601: 10^4 from the origin, where a hit's distance
+# is off its ray parameter by more than a relative bound on the distance allows (cull_bound)
+HARD_SEEDS = (range(*(int(x) for x in os.environ["MIRT_HARD_SEEDS"].split(":"))) if os.environ.get("MIRT_HARD_SEEDS")
+              else list(range(36)) + [138, 192, 433, 559, 601])
+
+
 @pytest.mark.parametrize("seed", SEEDS)
 def test_random_scene_matches_the_oracle(seed):
+    _check(seed, random_scene_text(seed))
+
+
+@pytest.mark.parametrize("seed", HARD_SEEDS)
+def test_hard_scene_matches_the_oracle(seed):
+    _check(seed, hard_scene_text(seed), scale=3 if seed % 6 != 4 else 1)
+
+
+def _check(seed, text, scale=5):
     from oracle.bind import CPort
     from raytracer_amd.device import DeviceScene, MirtError
-    fs = FlatScene.from_text(random_scene_text(seed))
+    fs = FlatScene.from_text(text)
     port = CPort(fs)
     want, wst = port.render()
-    W, H = fs.width * 5, fs.height * 5
+    W, H = fs.width * scale, fs.height * scale
     big, bst = port.render(W, H)
     libs = [None]
     if seed % 3 == 0:
