@@ -1489,6 +1489,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		}
 		sphKept += mCnt[d->sphere_prim[i]] != 0 ? 1u : 0u;
 	}
+	// D: how far a ray's origin can be from anything it is tested against -- rays start at the camera (slo/shi began there) or on a primitive
 	const float D = sqrtf((shi[0] - slo[0]) * (shi[0] - slo[0]) + (shi[1] - slo[1]) * (shi[1] - slo[1]) + (shi[2] - slo[2]) * (shi[2] - slo[2]));
 	const uint32_t triKept = chunkKept[triChunks];
 	bb.prims.resize((size_t)triKept + sphKept);
@@ -1517,10 +1518,25 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 		for (uint32_t i = 0; i < d->n_spheres; ++i) {
 			if (mCnt[d->sphere_prim[i]] == 0) continue;
 			BvhPrim p;
+			const mirt_sphere& sp = d->spheres[i];
+			// the largest stretch of the linear part of M^-1 is at most sqrt(largest column sum x largest row sum)
+			float colMax = 0.0f, rowMax = 0.0f;
+			for (int a = 0; a < 3; ++a) {
+				colMax = fmaxf(colMax, fabsf(sp.Minv[a * 4 + 0]) + fabsf(sp.Minv[a * 4 + 1]) + fabsf(sp.Minv[a * 4 + 2]));
+				rowMax = fmaxf(rowMax, fabsf(sp.Minv[0 * 4 + a]) + fabsf(sp.Minv[1 * 4 + a]) + fabsf(sp.Minv[2 * 4 + a]));
+			}
+			const float far = sqrtf(colMax * rowMax) * D;
 			for (int k = 0; k < 3; ++k) {
 				const float c = sphBox[(size_t)i * 6 + k], h = sphBox[(size_t)i * 6 + 3 + k];
-				const float ratio = h > 0.0f ? D / h : 0.0f;
-				const float pad = h * (0.01f + 4e-7f * ratio * ratio) + 1e-5f * (fabsf(c) + D) + 1e-7f;
+				// Sphere::intersect decides from b^2 - 4ac in OBJECT space (Sphere.cpp:60-66), where the ray's origin is up to
+				// far = |M^-1| D from the centre: the rounding of b and c leaves a noise of up to 8e-7 far^2 in the discriminant
+				// (a few ulps of b^2 ~ 4 far^2; 2e-7 far^2 is the most the random-scene tests have shown), so the test answers as if the radius were sqrt(r^2 + 8e-7 far^2) -- for a
+				// sphere flattened a thousandfold and seen from a few hundred units, hundreds of radii.  The hierarchy's box has to
+				// hold every point the reference can report, so it is the box of THAT sphere.
+				// (a radius of zero included: from 500 units away it is hit like any other.)
+				const float rowNorm = sqrtf(sp.M[0 * 4 + k] * sp.M[0 * 4 + k] + sp.M[1 * 4 + k] * sp.M[1 * 4 + k] + sp.M[2 * 4 + k] * sp.M[2 * 4 + k]);
+				const float hh = fmaxf(h, sqrtf(sp.radius * sp.radius + 8e-7f * (far * far)) * rowNorm);
+				const float pad = (std::isfinite(hh) ? hh - h : 0.0f) + h * 0.01f + 1e-5f * (fabsf(c) + D) + 1e-7f;
 				p.lo[k] = c - h - pad;
 				p.hi[k] = c + h + pad;
 			}

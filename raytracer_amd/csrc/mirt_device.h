@@ -67,7 +67,7 @@ struct DScene {
 	// (2) membership lists
 	const float4* memb;
 	unsigned long long* dbg; // diagnostic event counters (MIRT_STATS builds)
-	// What a ray whose direction is NaN "hits" in the reference (a light exactly at the hit point: normalize(0), main.cpp:222):
+	// What a ray whose direction (or origin) is NaN "hits" in the reference (a light exactly at the hit point: normalize(0), main.cpp:222):
 	// every box passes (AABB.cpp:60-72: no comparison with a NaN is true), no triangle does (Triangle.cpp:163-166), every
 	// sphere returns a NaN distance, which counts as valid (SceneObjects.hpp:35-37), and between two NaN answers a node takes
 	// the right one (Partition.cpp:47), a leaf the first (Partition.h:33): the first sphere of the last leaf that holds one.

@@ -109,7 +109,10 @@ __device__ __forceinline__ RayCtx make_ray(f3 o, f3 d) {
 __device__ __forceinline__ float cull_bound(const DScene& S, const RayCtx& r, float dist) {
 	return dist * r.invLen * 1.0001f + S.cullSlack;
 }
-__device__ __forceinline__ bool has_nan(f3 d) { return d.x != d.x || d.y != d.y || d.z != d.z; }
+// A ray without a direction or without an origin (see DScene::nanHit).  All three components: that is what normalize(0) and
+// a point on such a ray are; with only some of them NaN, what the reference's std::min / std::max keep depends on the operand
+// order, and the ordinary walk's comparisons -- false for every box -- give its answer (no hit) in the cases seen.
+__device__ __forceinline__ bool all_nan(f3 v) { return v.x != v.x && v.y != v.y && v.z != v.z; }
 
 // The direction with AABB.cpp:53-58's substitution: |d| < 1e-5 -> +1e-5.  Not kept in RayCtx: only the reference's own
 // box test needs it, and three registers held through the whole walk cost more than recomputing it there.
@@ -512,7 +515,7 @@ struct Walker {
 		best.pos = 0xffffffffu;
 		tcull = lim >= 0.0f ? cull_bound(S, r, lim) : __builtin_inff();
 		sp = 0;
-		if (has_nan(d)) { // see DScene::nanHit
+		if (all_nan(d) || all_nan(o)) { // see DScene::nanHit
 			best.ref = S.nanHit;
 			best.dist = __builtin_nanf("");
 			cur = BVH_DONE;
@@ -701,7 +704,7 @@ struct Walker {
 template <int MODE, bool OVF, class STK>
 __device__ __forceinline__ void trace_whole(const DScene& S, f3 o, f3 d, float limit, Hit& best, STK& stk) {
 	if (MODE == MODE_REFWALK) {
-		if (has_nan(d)) { // see DScene::nanHit
+		if (all_nan(d) || all_nan(o)) { // see DScene::nanHit
 			best.ref = S.nanHit;
 			best.dist = __builtin_nanf("");
 			best.pos = 0;

@@ -277,3 +277,131 @@ def hard_scene_text(seed):
             quad(c + np.array([-1.0, -1.0, 0.0]), np.array([2.0, 0, 0]), np.array([0, 2.0, 0]))  # through the sphere's centre
     out.append("maxverts %d" % max(1, len(verts)))
     return "\n".join(out + verts + body) + "\n"
+
+
+def nasty_scene_text(seed):
+    """Inputs on the edge of the scene language's meaning: a light direction of zero, an up vector along the view, fields of view of
+    0.001 and 179.999 degrees, zero and negative radii, mirrored and nearly flat transforms, shininess 0 and negative, light colours
+    that are negative or overflow, an attenuation that is zero everywhere, speculars above 1 at maxdepth 30, hundreds of coplanar
+    triangles answering at one distance.  What the reference makes of them is arbitrary but it is a function of the input, and
+    the library claims the same function."""
+    rng = np.random.default_rng(200000 + seed)
+    kind = seed % 8
+    out, verts, body = [], [], []
+
+    def vertex(p):
+        verts.append("vertex %s" % _vec(p))
+        return len(verts) - 1
+
+    def quad(p0, e1, e2):
+        a, b, c, d = vertex(p0), vertex(p0 + e1), vertex(p0 + e1 + e2), vertex(p0 + e2)
+        body.append("tri %d %d %d" % (a, b, c))
+        body.append("tri %d %d %d" % (a, c, d))
+
+    def material():
+        body.append("ambient %s" % _vec(rng.uniform(0, 0.2, 3)))
+        body.append("diffuse %s" % _vec(rng.uniform(0.1, 1, 3)))
+        body.append("specular %s" % _vec(rng.uniform(0.0, 0.9, 3)))
+        body.append("shininess %s" % _f(rng.choice([1, 10, 100])))
+
+    def some_geometry():
+        material()
+        quad(np.array([-3.0, -1.0, -3.0]), np.array([6.0, 0, 0]), np.array([0, 0, 6.0]))
+        for _ in range(int(rng.integers(1, 6))):
+            material()
+            body.append("sphere %s %s" % (_vec(rng.uniform(-1.5, 1.5, 3)), _f(rng.uniform(0.2, 0.8))))
+        for _ in range(int(rng.integers(0, 20))):
+            c = rng.uniform(-2, 2, 3)
+            idx = [vertex(c + rng.uniform(-0.7, 0.7, 3)) for _ in range(3)]
+            body.append("tri %d %d %d" % tuple(idx))
+
+    w, h = int(rng.integers(16, 64)), int(rng.integers(12, 48))
+    out += ["size %d %d" % (w, h), "maxdepth %d" % int(rng.integers(0, 6))]
+    cam = "camera %s 0 0 0 0 1 0 %s" % (_vec(rng.uniform(-1, 1, 3) + np.array([0, 0.5, 5.0])), _f(rng.uniform(30, 60)))
+    lights = ["point %s 1 1 1" % _vec(rng.uniform(-3, 3, 3) + np.array([0, 3, 2])), "directional 0.2 1 0.5 0.4 0.4 0.4"]
+    if kind == 0:  # light directions and positions without a direction
+        lights = ["directional 0 0 0 0.8 0.8 0.8", "point %s 1 1 1" % _vec(rng.uniform(-3, 3, 3) + np.array([0, 3, 2]))]
+        if rng.random() < 0.5:
+            lights.append("directional 1e-30 0 0 0.5 0.5 0.5")  # its squared length underflows to zero
+        some_geometry()
+        if rng.random() < 0.3:
+            body = [ln for ln in body if not ln.startswith("sphere")]  # the same without a sphere to "hit"
+    elif kind == 1:  # cameras without a frame, or with hardly any field of view, or nearly all of it
+        c = rng.integers(0, 4)
+        if c == 0:
+            cam = "camera 0 5 0 0 0 0 0 1 0 45"      # up along the view: cross(up, w) = 0
+        elif c == 1:
+            cam = "camera 0 0 5 0 0 5 0 1 0 45"      # looking at itself
+        elif c == 2:
+            cam = "camera 0 0.5 5 0 0 0 0 1 0 0.001"
+        else:
+            cam = "camera 0 0.5 5 0 0 0 0 1 0 179.999"
+        some_geometry()
+    elif kind == 2:  # radii and transforms that are hardly any
+        material()
+        body.append("sphere 0 0 0 0")
+        body.append("sphere 1 0 0 -0.5")
+        body.append("sphere -1 0 0 1e-4")
+        body.append("sphere 0 0 -2000 1990")
+        for sc in ("-1 1 1", "1 -1 -1", "1 1e-3 1", "1e3 1e3 1e3", "1e-3 1e-3 1e-3"):
+            material()
+            body.append("pushTransform")
+            body.append("translate %s" % _vec(rng.uniform(-1.5, 1.5, 3)))
+            body.append("scale %s" % sc)
+            body.append("sphere 0 0 0 %s" % _f(rng.choice([0.5, 5e-4 if sc.startswith("1e3") else 0.5, 500.0 if sc.startswith("1e-3") else 0.5])))
+            quad(np.array([-0.5, -0.5, 0.3]), np.array([1.0, 0, 0]), np.array([0, 1.0, 0]))
+            body.append("popTransform")
+    elif kind == 3:  # materials outside the usual ranges
+        for sh in (0, -2, 0.5, 1e4, 1e-3):
+            body.append("ambient %s" % _vec(rng.uniform(-0.2, 0.3, 3)))
+            body.append("diffuse %s" % _vec(rng.uniform(-0.5, 2.0, 3)))
+            body.append("specular %s" % _vec(rng.uniform(-0.5, 1.5, 3)))
+            body.append("emission %s" % _vec(rng.uniform(-0.2, 1.5, 3)))
+            body.append("shininess %s" % _f(sh))
+            body.append("sphere %s %s" % (_vec(rng.uniform(-2, 2, 3)), _f(rng.uniform(0.3, 0.9))))
+        quad(np.array([-3.0, -1.0, -3.0]), np.array([6.0, 0, 0]), np.array([0, 0, 6.0]))
+    elif kind == 4:  # lights outside the usual ranges, attenuations that divide by zero
+        lights = ["point 1 2 3 -1 0.5 2", "directional 0 1 0 1e30 1e30 1e30", "point -2 3 1 1e38 1e38 1e38", "point 0 4 0 3e38 0 0"]
+        out.append("attenuation %s" % rng.choice(["0 0 0", "0 0 1", "-1 0.5 0", "1e-30 0 0", "0 1e30 1e30"]))
+        some_geometry()
+    elif kind == 5:  # mirrors that gain energy, followed a long way
+        out[1] = "maxdepth %d" % int(rng.integers(12, 31))
+        body.append("ambient 0.05 0.05 0.05")
+        body.append("diffuse 0.2 0.2 0.2")
+        body.append("specular %s" % _vec(rng.uniform(0.9, 1.6, 3)))
+        body.append("shininess 50")
+        quad(np.array([-2.0, -2.0, -2.0]), np.array([4.0, 0, 0]), np.array([0, 4.0, 0]))
+        quad(np.array([-2.0, -2.0, 2.0]), np.array([0, 4.0, 0]), np.array([4.0, 0, 0]))
+        quad(np.array([-2.0, -2.0, -2.0]), np.array([0, 0, 4.0]), np.array([4.0, 0, 0]))
+        quad(np.array([-2.0, 2.0, -2.0]), np.array([4.0, 0, 0]), np.array([0, 0, 4.0]))
+        for _ in range(int(rng.integers(1, 5))):
+            body.append("sphere %s %s" % (_vec(rng.uniform(-1.2, 1.2, 3)), _f(rng.uniform(0.2, 0.6))))
+        cam = "camera %s 0 0 0 0 1 0 60" % _vec(rng.uniform(-0.5, 0.5, 3) + np.array([0, 0, 1.5]))
+        lights = ["point %s 1 1 1" % _vec(rng.uniform(-1, 1, 3))]
+    elif kind == 6:  # hundreds of coplanar triangles over one another: one distance, many answers
+        material()
+        n = int(rng.integers(50, 400))
+        z = float(rng.integers(-2, 2))
+        for i in range(n):
+            if rng.random() < 0.1:
+                material()
+            c = np.array([float(rng.integers(-8, 8)) * 0.25, float(rng.integers(-8, 8)) * 0.25, z])
+            idx = [vertex(c + np.array([float(rng.integers(-4, 5)) * 0.25, float(rng.integers(-4, 5)) * 0.25, 0.0])) for _ in range(3)]
+            body.append("tri %d %d %d" % tuple(idx))
+    else:  # everything at once, under a deep stack of transforms
+        material()
+        depth = int(rng.integers(3, 9))
+        for _ in range(depth):
+            body.append("pushTransform")
+            body.append("translate %s" % _vec(rng.uniform(-0.3, 0.3, 3)))
+            body.append("rotate %s %s" % (_vec(rng.uniform(-1, 1, 3) + np.array([0, 0, 1.2])), _f(rng.uniform(-60, 60))))
+            body.append("scale %s" % _vec(rng.choice([-1.0, 1.0], 3) * rng.uniform(0.7, 1.3, 3)))
+            if rng.random() < 0.5:
+                material()
+            body.append("sphere %s %s" % (_vec(rng.uniform(-1, 1, 3)), _f(rng.uniform(0.2, 0.6))))
+            quad(rng.uniform(-1, 1, 3), rng.uniform(-1, 1, 3), rng.uniform(-1, 1, 3))
+        body += ["popTransform"] * depth
+    out.append(cam)
+    out += lights
+    out.append("maxverts %d" % max(1, len(verts)))
+    return "\n".join(out + verts + body) + "\n"

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from random_scenes import hard_scene_text, random_scene_text
+from random_scenes import hard_scene_text, nasty_scene_text, random_scene_text
 from raytracer_amd import _capi
 from raytracer_amd.scene import FlatScene
 
@@ -41,7 +41,18 @@ def test_hard_scene_matches_the_oracle(seed):
     _check(seed, hard_scene_text(seed), scale=3 if seed % 6 != 4 else 1)
 
 
-def _check(seed, text, scale=5):
+# 458: a sphere flattened a thousandfold, "hit" by the reference 90 units from where it is (the discriminant's rounding noise in
+# object space); 642, 722: the same for a sphere of radius zero; 784: a light direction whose squared length underflows
+NASTY_SEEDS = (range(*(int(x) for x in os.environ["MIRT_NASTY_SEEDS"].split(":"))) if os.environ.get("MIRT_NASTY_SEEDS")
+               else list(range(48)) + [458, 642, 722, 784])
+
+
+@pytest.mark.parametrize("seed", NASTY_SEEDS)
+def test_nasty_scene_matches_the_oracle(seed):
+    _check(seed, nasty_scene_text(seed), scale=2, fast=False)
+
+
+def _check(seed, text, scale=5, fast=True):
     from oracle.bind import CPort
     from raytracer_amd.device import DeviceScene, MirtError
     fs = FlatScene.from_text(text)
@@ -70,10 +81,13 @@ def _check(seed, text, scale=5):
             o, d = port.primary_rays(fs.width, fs.height)
             ids, dist, _, _ = port.trace(o, d)
             gi, gd = s.trace_primary_ids()
-            assert np.array_equal(gi, ids) and np.array_equal(gd.view(np.uint32), dist.view(np.uint32))
+            nan = np.isnan(dist)  # (a NaN is a NaN: its sign and payload decide nothing)
+            assert np.array_equal(gi, ids) and np.array_equal(np.isnan(gd), nan) and np.array_equal(gd[~nan].view(np.uint32), dist[~nan].view(np.uint32))
             # MIRT_TRACE_FAST drops the leaf-box check: it sees every hit the reference sees, nothing nearer is lost, and more
             # only where the reference's tree cannot reach a primitive (the bounds the reference gives a rotated or scaled
             # sphere do not contain it, Sphere.cpp:13-41: the reference draws such a sphere clipped, FAST draws all of it)
+            if not fast:
+                continue
             fi, fd = s.trace_primary_ids(trace_mode=_capi.TRACE_FAST)
             assert not np.any((ids >= 0) & (fi < 0))
             both = (ids >= 0) & (fi >= 0)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle.bind import CPort, REF_LIB, RefOracle
-from random_scenes import hard_scene_text, random_scene_text
+from random_scenes import hard_scene_text, nasty_scene_text, random_scene_text
 from raytracer_amd.scene import FlatScene
 
 pytestmark = pytest.mark.skipif(not os.path.exists(REF_LIB), reason="reference build oracle/_ref not present")
@@ -23,6 +23,11 @@ def test_loader_and_restatement_match_the_reference_on_a_random_scene(seed, tmp_
 @pytest.mark.parametrize("seed", list(range(36)) + [138, 192, 433, 559, 601])
 def test_loader_and_restatement_match_the_reference_on_a_hard_scene(seed, tmp_path):
     _check(hard_scene_text(seed), tmp_path)
+
+
+@pytest.mark.parametrize("seed", list(range(48)) + [458, 642, 722, 784])
+def test_loader_and_restatement_match_the_reference_on_a_nasty_scene(seed, tmp_path):
+    _check(nasty_scene_text(seed), tmp_path)
 
 
 def _check(text, tmp_path):
