@@ -32,13 +32,13 @@ HARD_SEEDS = (range(*(int(x) for x in os.environ["MIRT_HARD_SEEDS"].split(":")))
 
 
 @pytest.mark.parametrize("seed", SEEDS)
-def test_random_scene_matches_the_oracle(seed):
-    _check(seed, random_scene_text(seed))
+def test_random_scene_matches_the_oracle(seed, tmp_path):
+    _check(seed, random_scene_text(seed), str(tmp_path))
 
 
 @pytest.mark.parametrize("seed", HARD_SEEDS)
-def test_hard_scene_matches_the_oracle(seed):
-    _check(seed, hard_scene_text(seed), scale=3 if seed % 6 != 4 else 1)
+def test_hard_scene_matches_the_oracle(seed, tmp_path):
+    _check(seed, hard_scene_text(seed), str(tmp_path), scale=3 if seed % 6 != 4 else 1)
 
 
 # 458: a sphere flattened a thousandfold, "hit" by the reference 90 units from where it is (the discriminant's rounding noise in
@@ -48,11 +48,11 @@ NASTY_SEEDS = (range(*(int(x) for x in os.environ["MIRT_NASTY_SEEDS"].split(":")
 
 
 @pytest.mark.parametrize("seed", NASTY_SEEDS)
-def test_nasty_scene_matches_the_oracle(seed):
-    _check(seed, nasty_scene_text(seed), scale=2, fast=False)
+def test_nasty_scene_matches_the_oracle(seed, tmp_path):
+    _check(seed, nasty_scene_text(seed), str(tmp_path), scale=2, fast=False)
 
 
-def _check(seed, text, scale=5, fast=True):
+def _check(seed, text, tmp_dir, scale=5, fast=True):
     from oracle.bind import CPort
     from raytracer_amd.device import DeviceScene, MirtError
     fs = FlatScene.from_text(text)
@@ -77,6 +77,41 @@ def _check(seed, text, scale=5, fast=True):
             img, st = s.render(W, H)
             assert np.array_equal(img, big), (seed, "x5", lib is not None)
             assert [st[k] for k in KEYS] == [bst[k] for k in KEYS]
+            if lib is None:
+                # one of the fifteen other feature sets, one of the six debug views (main.cpp:24-42)
+                f, dbg = seed % 15, seed % 6
+                a, ast = s.render(features=f)
+                b, bst2 = port.render(features=f)
+                assert np.array_equal(a, b), (seed, "features", f)
+                assert [ast[k] for k in KEYS] == [bst2[k] for k in KEYS]
+                a, _ = s.render(debug=dbg)
+                b, _ = port.render(debug=dbg)
+                assert np.array_equal(a, b), (seed, "debug", dbg)
+                # the other ways a frame can be run: one launch per depth, with and without lane refilling; hit records; shared walks (by
+                # default only hierarchies of 4096 nodes and more get them);
+                # instead of per-pixel slots; and the scene from its cache file
+                way = seed % 5
+                env = {0: {"MIRT_SINGLE_LAUNCH": "0"}, 1: {"MIRT_SINGLE_LAUNCH": "0", "MIRT_REFILL_MIN": "24"}, 2: {"MIRT_FRAME_RECORDS": "1"},
+                       3: {"MIRT_SHARE": "1"}, 4: {}}[way]
+                old = {k: os.environ.get(k) for k in env}
+                os.environ.update(env)
+                try:
+                    if way == 4:
+                        path = os.path.join(tmp_dir, "scene.mirt")
+                        s.save(path)
+                        s2, _ = DeviceScene.load(path, 0)
+                    else:
+                        s2 = DeviceScene(fs, 0)
+                    with s2:
+                        img, st = s2.render(W, H)
+                        assert np.array_equal(img, big), (seed, "way", way)
+                        assert [st[k] for k in KEYS] == [bst[k] for k in KEYS]
+                finally:
+                    for k, v in old.items():
+                        if v is None:
+                            os.environ.pop(k, None)
+                        else:
+                            os.environ[k] = v
             # the ids and distances of the camera rays, bit for bit
             o, d = port.primary_rays(fs.width, fs.height)
             ids, dist, _, _ = port.trace(o, d)
