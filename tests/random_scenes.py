@@ -405,3 +405,67 @@ def nasty_scene_text(seed):
     out += lights
     out.append("maxverts %d" % max(1, len(verts)))
     return "\n".join(out + verts + body) + "\n"
+
+
+def big_scene_text(seed):
+    """Tessellated surfaces of 5 000 to 60 000 triangles with shared vertices (a bumpy floor, tori, lumpy balls), a few real
+    spheres, several lights: Partition trees 20 to 40 levels deep, hierarchies beyond the 4096 nodes from which walks are shared
+    between lanes, walks long enough to overflow a small stack."""
+    rng = np.random.default_rng(300000 + seed)
+    out, verts, body = [], [], []
+
+    def vertex(p):
+        verts.append("vertex %s" % _vec(p))
+        return len(verts) - 1
+
+    def material():
+        body.append("ambient %s" % _vec(rng.uniform(0, 0.15, 3)))
+        body.append("diffuse %s" % _vec(rng.uniform(0.1, 0.9, 3)))
+        body.append("specular %s" % _vec(rng.uniform(0.0, 0.8, 3)))
+        body.append("shininess %s" % _f(rng.choice([5, 30, 120])))
+
+    def mesh(n, m, f, wrap_u=False, wrap_v=False):
+        nu, nv = (n if wrap_u else n + 1), (m if wrap_v else m + 1)
+        idx = [[vertex(f(i / float(n), j / float(m))) for j in range(nv)] for i in range(nu)]
+        for i in range(n):
+            for j in range(m):
+                a, b = idx[i][j], idx[(i + 1) % nu][j]
+                c, d = idx[(i + 1) % nu][(j + 1) % nv], idx[i][(j + 1) % nv]
+                body.append("tri %d %d %d" % (a, b, c))
+                body.append("tri %d %d %d" % (a, c, d))
+
+    w, h = int(rng.integers(60, 140)), int(rng.integers(40, 100))
+    out += ["size %d %d" % (w, h), "maxdepth %d" % int(rng.integers(1, 6))]
+    out.append("camera %s %s 0 1 0 %s" % (_vec(rng.uniform(-2, 2, 3) + np.array([0, 2.5, 9.0])), _vec(rng.uniform(-0.5, 0.5, 3)), _f(rng.uniform(30, 55))))
+    for _ in range(int(rng.integers(1, 5))):
+        out.append("point %s %s" % (_vec(rng.uniform(-6, 6, 3) + np.array([0, 6, 2])), _vec(rng.uniform(0.3, 0.9, 3))))
+    if rng.random() < 0.5:
+        out.append("directional %s 0.3 0.3 0.3" % _vec(rng.uniform(-1, 1, 3) + np.array([0, 1.5, 0.5])))
+    budget = int(rng.choice([5000, 12000, 30000, 60000]))
+    material()
+    n = int(np.sqrt(budget * 0.3))
+    fx, fz, amp = rng.uniform(0.5, 5), rng.uniform(0.5, 5), rng.uniform(0.05, 0.6)
+    mesh(n, n, lambda u, v: np.array([-6 + 12 * u, amp * np.sin(fx * u * 6.28) * np.sin(fz * v * 6.28) - 1.5, -6 + 12 * v]))
+    parts = int(rng.integers(2, 6))
+    for _ in range(parts):
+        material()
+        body.append("pushTransform")
+        body.append("translate %s" % _vec(rng.uniform(-3, 3, 3) + np.array([0, 0.5, 0])))
+        body.append("rotate %s %s" % (_vec(rng.uniform(-1, 1, 3) + np.array([0, 1.2, 0])), _f(rng.uniform(0, 360))))
+        k = int(np.sqrt(budget * 0.7 / parts / 2))
+        if rng.random() < 0.5:
+            R, r = rng.uniform(0.8, 1.6), rng.uniform(0.15, 0.5)
+            mesh(k, k, lambda u, v: np.array([(R + r * np.cos(6.283185 * v)) * np.cos(6.283185 * u), r * np.sin(6.283185 * v), (R + r * np.cos(6.283185 * v)) * np.sin(6.283185 * u)]), True, True)
+        else:
+            R, lump, fl = rng.uniform(0.5, 1.3), rng.uniform(0, 0.25), int(rng.integers(2, 9))
+            def ball(u, v):
+                th, ph = 6.283185 * u, 3.14159 * (0.02 + 0.96 * v)
+                rr = R * (1 + lump * np.sin(fl * th) * np.sin(fl * ph))
+                return np.array([rr * np.sin(ph) * np.cos(th), rr * np.cos(ph), rr * np.sin(ph) * np.sin(th)])
+            mesh(k, k, ball, True, False)
+        body.append("popTransform")
+    for _ in range(int(rng.integers(0, 6))):
+        material()
+        body.append("sphere %s %s" % (_vec(rng.uniform(-4, 4, 3)), _f(rng.uniform(0.2, 0.7))))
+    out.append("maxverts %d" % max(1, len(verts)))
+    return "\n".join(out + verts + body) + "\n"

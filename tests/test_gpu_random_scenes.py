@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from random_scenes import hard_scene_text, nasty_scene_text, random_scene_text
+from random_scenes import big_scene_text, hard_scene_text, nasty_scene_text, random_scene_text
 from raytracer_amd import _capi
 from raytracer_amd.scene import FlatScene
 
@@ -50,6 +50,14 @@ NASTY_SEEDS = (range(*(int(x) for x in os.environ["MIRT_NASTY_SEEDS"].split(":")
 @pytest.mark.parametrize("seed", NASTY_SEEDS)
 def test_nasty_scene_matches_the_oracle(seed, tmp_path):
     _check(seed, nasty_scene_text(seed), str(tmp_path), scale=2, fast=False)
+
+
+BIG_SEEDS = range(*(int(x) for x in os.environ["MIRT_BIG_SEEDS"].split(":"))) if os.environ.get("MIRT_BIG_SEEDS") else range(10)
+
+
+@pytest.mark.parametrize("seed", BIG_SEEDS)
+def test_big_scene_matches_the_oracle(seed, tmp_path):
+    _check(seed, big_scene_text(seed), str(tmp_path), scale=2)
 
 
 def _check(seed, text, tmp_dir, scale=5, fast=True):

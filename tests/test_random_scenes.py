@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle.bind import CPort, REF_LIB, RefOracle
-from random_scenes import hard_scene_text, nasty_scene_text, random_scene_text
+from random_scenes import big_scene_text, hard_scene_text, nasty_scene_text, random_scene_text
 from raytracer_amd.scene import FlatScene
 
 pytestmark = pytest.mark.skipif(not os.path.exists(REF_LIB), reason="reference build oracle/_ref not present")
@@ -28,6 +28,11 @@ def test_loader_and_restatement_match_the_reference_on_a_hard_scene(seed, tmp_pa
 @pytest.mark.parametrize("seed", list(range(48)) + [458, 642, 722, 784])
 def test_loader_and_restatement_match_the_reference_on_a_nasty_scene(seed, tmp_path):
     _check(nasty_scene_text(seed), tmp_path)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_loader_and_restatement_match_the_reference_on_a_big_scene(seed, tmp_path):
+    _check(big_scene_text(seed), tmp_path)
 
 
 def _check(text, tmp_path):
