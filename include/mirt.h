@@ -136,7 +136,12 @@ typedef struct mirt_scene_desc {
  *            its tree visits first); also ends a path at a material whose specular weight is zero instead of tracing the
  *            weightless reflection.  The triangle test is still the reference's (Triangle.cpp:147-171: plane hit and three
  *            signed-area edge tests), NOT Moeller-Trumbore: the mode relaxes which candidates count, never the arithmetic.
- *   REFWALK: walks the Partition tree that was handed over, box by box (cross-check and fallback; slow). */
+ *   REFWALK: walks the Partition tree that was handed over, box by box (cross-check and fallback; slow).  Its stack holds 94
+ *            levels: a render that asks for REFWALK on a deeper tree returns MIRT_E_INVALID (the other modes never walk that tree).
+ * In every mode a ray whose direction or origin is NaN in all three components -- the shadow ray towards a light that lies
+ * exactly at the hit point (normalize(0), main.cpp:222), every ray of a camera whose up vector lies along its view -- gets the
+ * reference's answer: it passes every box, no triangle, and every sphere, with a NaN distance that counts as a hit
+ * (SceneObjects.hpp:35-37). */
 #define MIRT_TRACE_EXACT 0u
 #define MIRT_TRACE_FAST 1u
 #define MIRT_TRACE_REFWALK 2u
