@@ -469,3 +469,51 @@ def big_scene_text(seed):
         body.append("sphere %s %s" % (_vec(rng.uniform(-4, 4, 3)), _f(rng.uniform(0.2, 0.7))))
     out.append("maxverts %d" % max(1, len(verts)))
     return "\n".join(out + verts + body) + "\n"
+
+
+# ---- malformed text: what the reference's parser makes of it (Scene.cpp:15-224, readvals :226-246) ------------------------------
+NUMS = ["1.", ".5", "+2", "-.5", "1e0", "1E+0", "0x10", "1f", "1,5", "nan", "inf", "-inf", "1e40", "1e-50", "1e-40", "--1", "1-", "1e", "1e+", "007", "1.5.5",
+        "1d0", "0.1e1x", "", " ", "\t", "NaN", "INF", "infinity", ".", "-", "+", "1_0", "٣", "1\r"]
+
+
+def mutate(text, rng):
+    lines = text.split("\n")
+    for _ in range(int(rng.integers(1, 6))):
+        k = int(rng.integers(0, len(lines)))
+        ln = lines[k]
+        cmd = ln.split(" ")[0]
+        if cmd in ("tri", "maxverts", "maxvertnorms", "size"):   # integer arguments: out-of-range indices are undefined behaviour
+            continue
+        what = int(rng.integers(0, 9))
+        tok = ln.split(" ")
+        if what == 0 and len(tok) > 1:
+            tok[int(rng.integers(1, len(tok)))] = NUMS[int(rng.integers(0, len(NUMS)))]
+        elif what == 1 and len(tok) > 1:
+            del tok[int(rng.integers(1, len(tok)))]
+        elif what == 2:
+            tok.insert(int(rng.integers(1, len(tok) + 1)), NUMS[int(rng.integers(0, len(NUMS)))])
+        elif what == 3:
+            tok[0] = tok[0].upper() if rng.random() < 0.5 else tok[0] + "x"
+        elif what == 4:
+            tok[0] = (" " if rng.random() < 0.5 else "\t") + tok[0]
+        elif what == 5:
+            tok = [" ".join(tok).replace(" ", "\t" if rng.random() < 0.5 else "  ")]
+        elif what == 6:
+            tok[-1] = tok[-1] + ("\r" if rng.random() < 0.5 else " \t ")
+        elif what == 7:
+            tok = ["#" + " ".join(tok)] if rng.random() < 0.5 else [" #" + " ".join(tok)]
+        else:
+            lines.insert(k, ["pushTransform", "popTransform", "popTransform", "translate 1 2", "scale 2 2 2", "rotate 0 0 0 45", "rotate 0 0 1 nan",
+                             "ambient .1 .2 .3", "emission 1 1", "attenuation 1 0", "maxdepth", "maxdepth 2.7", "maxdepth -3", "output x y", "sphere 0 0 0",
+                             "sphere 0 0 0 1 5", "point 1 2 3 1 1", "directional 1 2 3 1 1 1 9", "camera 0 0 1 0 0 0 0 1 0", "vertex 1 2", "shininess"][int(rng.integers(0, 21))])
+            continue
+        lines[k] = " ".join(tok)
+    return "\n".join(lines)
+
+
+def mutated_scene_text(seed):
+    """One of the first 48 plain scenes with one to five lines damaged: numbers in every spelling a stream may or may not read,
+    tokens missing or too many, commands in the wrong case or indented, tabs, carriage returns, comment signs in and out of
+    column 0, stray stack commands and short argument lists.  (Lines with integer arguments are left alone: an index out of
+    range is undefined behaviour in the reference.)"""
+    return mutate(random_scene_text(seed % 48), np.random.default_rng(900000 + seed))
