@@ -13,7 +13,7 @@ import sys
 path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracer_amd", "csrc", "mirt_gfx950.s")
 want = sys.argv[2:] or ["_Z7k_frameILi0ELb0ELb1ELb0E", "_Z7k_frameILi0ELb1ELb1ELb0E", "_Z7k_frameILi0ELb0ELb0ELb0E"]
 s = open(path).read()
-for m in re.finditer(r"^(_Z\w+):\s*$", s, re.M):
+for m in re.finditer(r"^(_Z\w+):", s, re.M):
     name = m.group(1)
     if not any(w in name for w in want):
         continue
