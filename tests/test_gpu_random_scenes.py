@@ -120,6 +120,15 @@ def _check(seed, text, tmp_dir, scale=5, fast=True):
                             os.environ.pop(k, None)
                         else:
                             os.environ[k] = v
+            if lib is None and seed % 4 == 1:
+                # one rank's share of the frame (every third 16x8 tile): the same share of the oracle's, black elsewhere
+                for first in range(3):
+                    part = np.full((H, W, 3), 9, np.uint8)
+                    s.render(W, H, out=part, tile_w=16, tile_h=8, first_tile=first, tile_stride=3)
+                    tiles = (np.arange(H)[:, None] // 8) * ((W + 15) // 16) + np.arange(W)[None, :] // 16
+                    mine = tiles % 3 == first
+                    assert np.array_equal(part[mine], big[mine]), (seed, "share", first)
+                    assert np.all(part[~mine] == 9), (seed, "outside the share", first)
             # the ids and distances of the camera rays, bit for bit
             o, d = port.primary_rays(fs.width, fs.height)
             ids, dist, _, _ = port.trace(o, d)
