@@ -1591,8 +1591,18 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 			if (MODE == MODE_EXACT) {
 				const bool redo = walk && !w.verify(S);
 				if (__builtin_amdgcn_ballot_w64(redo)) {
+#if MIRT_TIMELINE
+					const unsigned long long tRedo = wall_clock64(); // S.dbg[0..3]: strict second walks, their summed and longest time, their rays
+#endif
 					if (redo) w.start(S, w.r.o, w.r.d, w.limit);
 					walk_wave<false, true>(S, w, stk);
+#if MIRT_TIMELINE
+					if (lane == 0) {
+						const unsigned long long dt = wall_clock64() - tRedo;
+						atomicAdd(S.dbg + 0, 1ull); atomicAdd(S.dbg + 1, dt); atomicMax(S.dbg + 2, dt);
+						atomicAdd(S.dbg + 3, (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(redo)));
+					}
+#endif
 				}
 			}
 		}
@@ -1724,6 +1734,12 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 		atomicAdd(S.dbg + 20, tEnd - tStart);
 		atomicAdd(S.dbg + 21, tEnd - tExhausted);
 		atomicAdd(S.dbg + 22, 1ull);
+#if MIRT_TIMELINE
+		if (wave < 8192u) { // per wave: start, end, when it found the slots exhausted, rounds | longest round << 32
+			const unsigned long long longest = tRoundMax[0] > tRoundMax[1] ? (tRoundMax[0] > tRoundMax[2] ? tRoundMax[0] : tRoundMax[2]) : (tRoundMax[1] > tRoundMax[2] ? tRoundMax[1] : tRoundMax[2]);
+			S.dbg[40 + 4 * wave] = tStart; S.dbg[41 + 4 * wave] = tEnd; S.dbg[42 + 4 * wave] = tExhausted; S.dbg[43 + 4 * wave] = (unsigned long long)nRounds | (longest << 32);
+		}
+#endif
 		atomicAdd(S.dbg + 23, (unsigned long long)nRounds);
 		atomicAdd(S.dbg + 24, (unsigned long long)nLaneRounds);
 		for (int k = 0; k < 3; ++k) {
