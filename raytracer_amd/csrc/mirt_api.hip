@@ -319,6 +319,7 @@ struct BlockList {
 	DevBuf list;
 	uint32_t count = 0;
 	bool all = false; // every block is visible (or the scene reaches behind the eye plane): no list is used
+	bool deep = false; // a second copy of the list follows the first: the blocks deepest inside the visible region first
 };
 
 struct mirt_scene {
@@ -1098,13 +1099,43 @@ const BlockList* visible_blocks(mirt_scene* s, const mirt_render_params* p, cons
 	for (uint64_t i = 0; i < nBlocks; ++i) if (mark[i]) list.push_back((uint32_t)i);
 	if (list.size() == nBlocks) return nullptr; // everything is visible: no list needed
 	if (list.empty()) list.push_back(0);         // nothing is: one block keeps the launch simple
+	const size_t count = list.size();
+	// A second order for a frame that has the GPU to itself (see enqueue_frame): the blocks deepest inside the visible region
+	// first -- where every camera ray hits and the paths are long -- and the region's rim, whose batches are done in a round or
+	// two, last.  Depth = rounds of peeling the region's edge blocks away (whole-image layout only).
+	if (p->tile_stride == 1 && !packed && count >= 1024) {
+		const uint32_t bw = (p->width + 7) / 8, bh = (p->height + 7) / 8;
+		auto blockOf = [&](uint32_t bx, uint32_t by) -> uint64_t { // the slot order: tiles row-major, 8x8 blocks row-major inside a tile
+			const uint32_t tx = bx * 8 / tileW, sx = (bx * 8 % tileW) / 8, ty = by * 8 / tileH, sy = (by * 8 % tileH) / 8;
+			return ((uint64_t)ty * g.tilesX + tx) * perTile + (uint64_t)sy * sbx + sx;
+		};
+		auto vis = [&](int bx, int by) { if (bx < 0 || by < 0 || bx >= (int)bw || by >= (int)bh) return false; const uint64_t b = blockOf(bx, by); return b < nBlocks && mark[b] != 0; };
+		std::vector<uint16_t> depth(nBlocks, 0);
+		std::vector<uint32_t> cur, next;
+		for (uint32_t by = 0; by < bh; ++by) for (uint32_t bx = 0; bx < bw; ++bx)
+			if (vis(bx, by) && !(vis(bx - 1, by) && vis(bx + 1, by) && vis(bx, by - 1) && vis(bx, by + 1))) { depth[blockOf(bx, by)] = 1; cur.push_back(by * bw + bx); }
+		for (uint16_t d = 1; !cur.empty() && d < 60000; ++d) {
+			next.clear();
+			for (uint32_t c : cur) {
+				const int bx = c % bw, by = c / bw;
+				const int nb[4][2] = {{bx - 1, by}, {bx + 1, by}, {bx, by - 1}, {bx, by + 1}};
+				for (auto& q : nb) if (vis(q[0], q[1]) && depth[blockOf(q[0], q[1])] == 0) { depth[blockOf(q[0], q[1])] = d + 1; next.push_back(q[1] * bw + q[0]); }
+			}
+			cur.swap(next);
+		}
+		std::vector<uint32_t> deep(list);
+		std::stable_sort(deep.begin(), deep.end(), [&](uint32_t a, uint32_t b) { return depth[a] > depth[b]; });
+		list.insert(list.end(), deep.begin(), deep.end());
+		bl->deep = true;
+	}
 	if (bl->list.ensure(list.size() * 4) != MIRT_OK || hipMemcpy(bl->list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
 		(void)hipGetLastError();
+		bl->deep = false;
 		return nullptr;
 	}
-	bl->count = (uint32_t)list.size();
+	bl->count = (uint32_t)count;
 	bl->all = false;
-	if (getenv("MIRT_VERBOSE")) fprintf(stderr, "mirt: %ux%u: %zu of %llu pixel blocks can see the scene (%zu boxes)\n", p->width, p->height, list.size(), (unsigned long long)nBlocks, s->cutBoxes.size() / 6);
+	if (getenv("MIRT_VERBOSE")) fprintf(stderr, "mirt: %ux%u: %zu of %llu pixel blocks can see the scene (%zu boxes)\n", p->width, p->height, count, (unsigned long long)nBlocks, s->cutBoxes.size() / 6);
 	return bl;
 }
 
@@ -1136,10 +1167,20 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 	F.preCleared = (packed || p->tile_stride == 1) ? 1u : 0u;
 	F.blockList = nullptr;
 	F.nListed = 0;
+	F.pullBelow = 64;
 	F.wideClear = (((uintptr_t)d_out & 3u) == 0 && (packed || (p->width & 3u) == 0)) ? 1u : 0u;
 	// A camera ray that misses the scene's bounds hits nothing, and with the output cleared beforehand its pixel needs no
 	// visit at all: k_frame is handed the list of the 8x8 pixel blocks that can see the scene (visible_blocks).
 	uint32_t nBatchesFrame = (uint32_t)(((uint64_t)F.nSlots + 63u) / 64u);
+	// A frame that has the GPU to itself is as long as its busiest wave: the batches with the long paths go out first, and a wave
+	// takes more pixel slots only when it holds few hits (with frames of other streams beside it, full rounds count for more).
+	// Stanford dragon 3840x2160 alone: 1.56-1.59 ms -> 1.47 with the threshold at 16-24 hits (32: 1.51, 8: 1.51, 1: 1.49) -> 1.44-1.45
+	// with the order as well (the order without the threshold: 1.57); 7680x4320 3.59 -> 3.40, 1200 spheres 0.665 -> 0.62, Cornell box
+	// 0.515 -> 0.49.  The waves that end last were those that kept taking slots while they held hits with long paths ahead
+	// (scripts/frame_timeline.py: 28 rounds against a mean of 16).  MIRT_ALONE=0 switches both off, MIRT_PULL_BELOW=n sets the threshold.
+	static const int aloneEnv = []() { const char* e = getenv("MIRT_ALONE"); return e && *e ? atoi(e) : 1; }();
+	const bool alone = single && othersInFlight == 0 && aloneEnv != 0;
+	bool deepOrder = false;
 	const char* cikEarly = getenv("MIRT_CLEAR_IN_KERNEL");
 	if (single && F.preCleared && !(cikEarly && *cikEarly == '1')) {
 		const char* re = getenv("MIRT_BLOCK_LIST"); // (read per frame: tests switch it)
@@ -1149,6 +1190,7 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 				F.blockList = (const uint32_t*)bl->list.p;
 				F.nListed = bl->count;
 				nBatchesFrame = bl->count;
+				if (alone && bl->deep) { F.blockList += bl->count; deepOrder = true; }
 			}
 		}
 	}
@@ -1162,7 +1204,11 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 	if (single) {
 		static const int parts = []() { const char* e = getenv("MIRT_BATCH_STRIDE"); const int v = e ? atoi(e) : 128; return v < 0 ? 0 : v; }(); // (a number: that fraction of the frame)
 		const uint64_t nb = nBatchesFrame;
-		if (parts && nb >= 16384) {
+		if (alone) {
+			static const int pull = []() { const char* e = getenv("MIRT_PULL_BELOW"); const int v = e ? atoi(e) : 20; return v >= 1 && v <= 64 ? v : 20; }();
+			F.pullBelow = (uint32_t)pull;
+		}
+		if (parts && nb >= 16384 && !deepOrder) {
 			uint64_t m = (nb / (uint64_t)parts) | 1u;
 			auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
 			while (gcd(m, nb) != 1) m += 2;

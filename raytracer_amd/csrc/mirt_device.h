@@ -110,6 +110,7 @@ struct DFrame {
 	float4* litL;      // [depth][slot] light sum of the hit at that depth
 	float4* litS;      // [depth][slot] mat.specular of that hit (weight of the next bounce)
 	uint32_t nRec;     // k_frame: stride of litL's depth index = entries of hitO/hitD/hitN (pixel slots, or records of the launch)
+	uint32_t pullBelow; // k_frame: a wave takes the next batch of pixel slots while it holds fewer hits than this (64, or less: see enqueue_frame)
 	uint32_t* counters; // see CTR_* below
 	uint32_t* countersNext; // k_frame: the counter block of the stream's next frame, cleared by this one (or NULL)
 	// Traversal-stack overflow area (entries beyond the LDS part), [level][thread of the launch].  It belongs to the

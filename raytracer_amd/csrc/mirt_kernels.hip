@@ -1478,7 +1478,7 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 		w.needStrict = false;
 		w.tcull = 0.0f;
 		if (!inBatch) {
-			if (nbuf < 64u && !pfirst) {
+			if (nbuf < F.pullBelow && !pfirst) {
 				pbatch = nBatches;
 				while (pcurTried < CTR_F_NCUR) {
 					uint32_t t = 0;
@@ -1489,7 +1489,7 @@ __global__ __launch_bounds__(FRAME_BLOCK) __attribute__((amdgpu_waves_per_eu(MIR
 					++pcurTried;
 				}
 			}
-			if (nbuf < 64u && pbatch < nBatches) {
+			if (nbuf < F.pullBelow && pbatch < nBatches) {
 				// up to 64 camera rays (main.cpp:152-153, depth 0)
 				round = ROUND_PRIMARY;
 				pfirst = false;
