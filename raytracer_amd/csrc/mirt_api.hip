@@ -149,7 +149,11 @@ inline h3 hnorm(h3 a) { float s = 1.0f / sqrtf(hdot(a, a)); return H3(a.x * s, a
 
 // Working set of the frames issued on one stream.  Frames on different streams own different workspaces, so they may
 // overlap on the GPU (the short, latency-bound deep-bounce launches of one frame run beside the bulk of the next).
+#if MIRT_TIMELINE
+#define DBG_WORDS (40 + 4 * 8192) // (timeline builds: four words per wave of a k_frame launch behind the counters, query 1000 + i)
+#else
 #define DBG_WORDS 40      // 64-bit words of mirt_scene::dbg: 0..31 event counters of diagnostic builds, 32..33 the clock probe
+#endif
 #define DBG_CLOCK 32
 
 struct FrameCtx {
@@ -2238,6 +2242,16 @@ int mirt_scene_query(mirt_scene* s, uint32_t what, uint64_t* v) {
 			*v = x;
 			break;
 		}
+#if MIRT_TIMELINE
+		if (what >= 1000 && what < 1000 + 4 * 8192) {
+			unsigned long long x = 0;
+			HIPCHK(hipSetDevice(s->device));
+			HIPCHK(hipDeviceSynchronize());
+			HIPCHK(hipMemcpy(&x, (char*)s->dbg.p + (40 + what - 1000) * 8, 8, hipMemcpyDeviceToHost));
+			*v = x;
+			break;
+		}
+#endif
 		if (what >= 100 && what < 116) { // diagnostic event counters of MIRT_STATS builds (read and clear)
 			unsigned long long x = 0;
 			HIPCHK(hipSetDevice(s->device));

@@ -15,7 +15,7 @@ lib = _capi.load_library(os.environ.get("MIRT_TIMELINE_LIB") or os.path.join(ROO
 flat = FlatScene.from_text(workloads.dragon(w, h))
 def q(s, k):
     v = C.c_uint64()
-    assert lib.mirt_scene_query(s.h, k, C.byref(v)) == 0
+    assert lib.mirt_scene_query(s.h, k, C.byref(v)) == 0, lib.mirt_last_error()
     return v.value
 with DeviceScene(flat, 0, lib=lib) as s:
     s.render(w, h)
