@@ -900,6 +900,10 @@ __device__ __forceinline__ void walk_wave_share(const DScene& S, Walker<MODE, OV
 	bool shared = false; // (uniform) some ray of the wave is walked by more than one lane
 	int gap = MIRT_SHARE_GAP - MIRT_SHARE_FIRST; // (uniform)
 	s_cull[lane] = __float_as_uint(w.tcull);
+#if MIRT_TIMELINE >= 2
+	uint32_t tlIters = 0, tlBusy = 0; // S.dbg[4..7]: the longest walk of a wave in iterations, all iterations, walks, walks of more than 200 iterations
+	struct TlEnd { const DScene& S; uint32_t& it; uint32_t& busy; uint32_t lane; __device__ ~TlEnd() { if (lane == 0) { atomicMax(S.dbg + 4, (unsigned long long)it); atomicAdd(S.dbg + 5, (unsigned long long)it); atomicAdd(S.dbg + 6, 1ull); if (it > 200u) { atomicAdd(S.dbg + 7, 1ull); atomicAdd(S.dbg + 8, (unsigned long long)busy); } } } } tlEnd{S, tlIters, tlBusy, lane};
+#endif
 	for (;;) {
 		// (asking for the group's bound here and using it after the step, so that the step's loads hide the LDS latency, was
 		// slower: 13.9 against 14.25 Grays/s on the Stanford dragon)
@@ -912,6 +916,9 @@ __device__ __forceinline__ void walk_wave_share(const DScene& S, Walker<MODE, OV
 		const bool wantNode = c >= 0, wantLeaf = c < -1;
 		const uint32_t nNode = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(wantNode)), nLeaf = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(wantLeaf));
 		if (nNode + nLeaf == 0u) break;
+#if MIRT_TIMELINE >= 2
+		++tlIters; tlBusy += nNode + nLeaf;
+#endif
 #if MIRT_TIMELINE >= 2 // (atomics on one word each per wave iteration: this build's times are many times the library's)
 		{
 			// idle lanes of this iteration by kind: holding a hit of their own / owners that gave work away / free to help

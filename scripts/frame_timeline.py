@@ -29,6 +29,9 @@ with DeviceScene(flat, 0, lib=lib) as s:
     print("waves %d, mean lifetime %.0f us, mean time after exhaustion %.0f us, rounds per wave %.1f, lanes per round %.1f" % (waves, us(life / waves), us(tail / waves), rounds / waves, lanes / max(1, rounds)))
     mx = [q(s, k) for k in range(149, 152)]; sm = [q(s, k) for k in range(152, 155)]
     print("longest round (camera, light, reflection) %s us; share of the summed round time %s" % ([round(us(x)) for x in mx], [round(x / max(1, sum(sm)), 3) for x in sm]))
+    it = [q(s, k) for k in range(104, 109)]
+    print("(-DMIRT_TIMELINE=2 only) walks of a wave (shared): %d, %.1f iterations on average, the longest %d; %d walks of more than 200 iterations, in which %.1f lanes were busy on average" % (
+        it[2], it[1] / max(1, it[2]), it[0], it[3], it[4] / max(1.0, float(it[3])) / 200.0))
     redo = [q(s, k) for k in range(100, 104)]
     print("strict second walks: %d rounds held up by %d rays, %.0f us in all (%.2f us per wave of the launch), longest %.0f us" % (redo[0], redo[3], us(redo[1]), us(redo[1]) / waves, us(redo[2])))
     r = [q(s, k) for k in range(108, 116)]
