@@ -135,6 +135,33 @@ def _check(seed, text, tmp_dir, scale=5, fast=True):
             gi, gd = s.trace_primary_ids()
             nan = np.isnan(dist)  # (a NaN is a NaN: its sign and payload decide nothing)
             assert np.array_equal(gi, ids) and np.array_equal(np.isnan(gd), nan) and np.array_equal(gd[~nan].view(np.uint32), dist[~nan].view(np.uint32))
+            # Scene::findClosestIntersection (Scene.h:37) for rays from anywhere: origins in and around the scene, directions of
+            # every length, axis-parallel ones, components below the 1e-5 that AABB.cpp:53-58 replaces -- ids, distances and
+            # normals bit for bit, in both modes that promise them
+            rng = np.random.default_rng(seed)
+            lo = fs.tri_verts.reshape(-1, 3).min(axis=0) if len(fs.tri_verts) else np.full(3, -2.0, np.float32)
+            hi = fs.tri_verts.reshape(-1, 3).max(axis=0) if len(fs.tri_verts) else np.full(3, 2.0, np.float32)
+            mid, half = (lo + hi) / 2, np.maximum((hi - lo) / 2, 1.0)
+            n = 1500
+            ro = (mid + rng.uniform(-1.5, 1.5, (n, 3)) * half).astype(np.float32)
+            rd = rng.normal(size=(n, 3)).astype(np.float32)
+            rd[0::5] /= np.linalg.norm(rd[0::5], axis=1, keepdims=True)
+            rd[1::5] *= (10.0 ** rng.uniform(-3, 3, (len(rd[1::5]), 1))).astype(np.float32)
+            rd[2::25, 0] = 0.0
+            rd[3::25, 1] = 0.0
+            rd[3::25, 2] = 0.0
+            rd[4::25, 2] = np.float32(3e-6)
+            rd[9::25, 0] = np.float32(-9.9e-6)
+            want_ids, want_dist, want_n, _ = port.trace(ro, rd)
+            for mode in (_capi.TRACE_EXACT, _capi.TRACE_REFWALK):
+                if mode == _capi.TRACE_REFWALK and s.query()["tree_wide_depth"] + 2 > 96:
+                    continue
+                gi, gd, gn = s.trace_rays(ro, rd, trace_mode=mode)
+                nan = np.isnan(want_dist)
+                assert np.array_equal(gi, want_ids), (seed, "rays", mode)
+                assert np.array_equal(np.isnan(gd), nan) and np.array_equal(gd[~nan].view(np.uint32), want_dist[~nan].view(np.uint32)), (seed, "ray distances", mode)
+                hit = (want_ids >= 0) & ~nan
+                assert np.array_equal(gn[hit].view(np.uint32), want_n[hit].view(np.uint32)), (seed, "ray normals", mode)
             # MIRT_TRACE_FAST drops the leaf-box check: it sees every hit the reference sees, nothing nearer is lost, and more
             # only where the reference's tree cannot reach a primitive (the bounds the reference gives a rotated or scaled
             # sphere do not contain it, Sphere.cpp:13-41: the reference draws such a sphere clipped, FAST draws all of it)
