@@ -80,7 +80,10 @@ static int box_hit(const float* bmin, const float* bmax, const ray_t* r) {
 	float tmax = minf_std(minf_std(maxf_std(t1, t2), maxf_std(t3, t4)), maxf_std(t5, t6)); /* :61 */
 	if ((double)tmax < 0.0001) return 0; /* :65 -- the literal there is a double */
 	if (tmin > tmax) return 0;            /* :70 */
-	return 1;
+	float t_result = tmin;                /* :73 */
+	if (tmin < 0.0001f) t_result = tmax;  /* :76-78 */
+	return !isinf(t_result);              /* what Partition.cpp:36 asks of the returned Intersection(t_result, ...): SceneObjects.hpp:35-37
+	                                         (an empty scene's root box is +inf .. -inf: every t is infinite) */
 }
 
 /* ---- Triangle::intersect (Triangle.cpp:147-175) --------------------------------------------------------- */

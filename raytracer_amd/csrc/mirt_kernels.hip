@@ -149,7 +149,10 @@ __device__ __forceinline__ bool box_hit(const RayCtx& r, const f3& e, f3 lo, f3 
 	// (0.0001f < 0.0001 < nextafterf(0.0001f)).
 	if (tmax <= 0.0001f) return false;
 	if (tmin > tmax) return false; // :70
-	return true;
+	// :73-78, Partition.cpp:36: the box counts if the Intersection it returns is valid, i.e. its distance -- tmin, or tmax
+	// when tmin lies behind the origin -- is not infinite (an empty scene's root box is +inf .. -inf; a NaN counts)
+	const float tResult = tmin < 0.0001f ? tmax : tmin;
+	return !isinf(tResult);
 }
 
 // Triangle::intersect (Triangle.cpp:147-175) on the precomputed records.  Returns the hit distance or -1.

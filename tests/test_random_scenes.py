@@ -50,6 +50,23 @@ def _check(text, tmp_path):
     got, gst = CPort(fs).render()
     assert np.array_equal(want, got)
     assert [wst["primary"], wst["shadow"], wst["reflection"]] == [gst[k] for k in ("primary_rays", "shadow_rays", "reflection_rays")]
+    # rays from anywhere (the same recipe as the GPU side): the reference's own findClosestIntersection against the restatement
+    rng = np.random.default_rng(len(text))
+    n = 600
+    ro = rng.uniform(-4, 4, (n, 3)).astype(np.float32)
+    rd = rng.normal(size=(n, 3)).astype(np.float32)
+    rd[0::5] /= np.linalg.norm(rd[0::5], axis=1, keepdims=True)
+    rd[1::5] *= (10.0 ** rng.uniform(-3, 3, (len(rd[1::5]), 1))).astype(np.float32)
+    rd[2::25, 0] = 0.0
+    rd[3::25, 1] = 0.0
+    rd[3::25, 2] = 0.0
+    rd[4::25, 2] = np.float32(3e-6)
+    ids, dist, nrm, vis = ref.trace(ro, rd)
+    ids2, dist2, nrm2, vis2 = CPort(fs).trace(ro, rd)
+    nan = np.isnan(dist)
+    assert np.array_equal(ids, ids2) and np.array_equal(np.isnan(dist2), nan) and np.array_equal(dist[~nan].view(np.uint32), dist2[~nan].view(np.uint32))
+    hit = (ids >= 0) & ~nan
+    assert np.array_equal(nrm[hit].view(np.uint32), nrm2[hit].view(np.uint32)) and np.array_equal(vis, vis2)
     ref.close()
 
 
