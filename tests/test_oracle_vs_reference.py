@@ -100,3 +100,34 @@ def test_cpu_rows_workers_cover_the_sample_once(tmp_path):
                                       check=True, capture_output=True, timeout=120).stdout) for p in range(P)]
     assert sum(o["rays"] for o in outs) == whole["primary"] + whole["shadow"] + whole["reflection"]
     assert all(o["seconds"] > 0 for o in outs)
+
+
+def test_rays_with_nan_infinite_and_tiny_components(tmp_path):
+    """Rays no frame produces: components that are NaN, infinite, signed zeros, 1e-30, 1e30, 1e38.  What the reference makes of
+    them hangs on the operand order of its std::min / std::max and on NaN distances counting as hits (SceneObjects.hpp:35-37);
+    the restatement must follow it there too: ids, distance bits and visit counts."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from random_scenes import hard_scene_text, nasty_scene_text, random_scene_text
+    from raytracer_amd.scene import FlatScene
+    rng = np.random.default_rng(5)
+    specials = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-30, -1e-30, 1e30, 1e38, 3e-6, 1.0, -1.0], np.float32)
+    for gen, seeds in ((random_scene_text, range(0, 12)), (hard_scene_text, range(0, 6)), (nasty_scene_text, range(0, 8))):
+        for seed in seeds:
+            text = gen(seed)
+            p = tmp_path / "s.test"
+            p.write_text(text)
+            ref = RefOracle(str(p))
+            n = 300
+            ro = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+            rd = rng.normal(size=(n, 3)).astype(np.float32)
+            for k in range(n):
+                for _ in range(int(rng.integers(0, 4))):
+                    (rd if rng.random() < 0.5 else ro)[k, rng.integers(0, 3)] = specials[rng.integers(0, len(specials))]
+            ids, dist, _, vis = ref.trace(ro, rd)
+            ids2, dist2, _, vis2 = CPort(FlatScene.from_text(text)).trace(ro, rd)
+            nan = np.isnan(dist)
+            assert np.array_equal(ids, ids2), (gen.__name__, seed)
+            assert np.array_equal(np.isnan(dist2), nan) and np.array_equal(bits(dist[~nan]), bits(dist2[~nan])), (gen.__name__, seed)
+            assert np.array_equal(vis, vis2), (gen.__name__, seed)
+            ref.close()
