@@ -1851,6 +1851,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
 	// the most entries a walk can hold: along any path, every node leaves behind all its children but one
 	const uint32_t stackNeed = bvhMaxStack + 1u;
 	s->diag[6] = stackNeed;
+	if (getenv("MIRT_VERBOSE")) fprintf(stderr, "mirt: hierarchy of %zu wide nodes, %u levels; a walk's stack can hold %u entries\n", bvhWide.size() / 16, bvhWideDepth, stackNeed);
 	// Every kernel keeps at least this many entries in LDS (each variant its own number), so an area sized for the smaller
 	// number serves all of them, and a hierarchy that fits the smaller number needs no overflow variant anywhere.
 	const uint32_t ldsEntries = std::min(std::min((uint32_t)STACK_LDS_REFILL, (uint32_t)STACK_LDS), (uint32_t)STACK_LDS_FRAME);
