@@ -4,7 +4,7 @@
   python bench.py --gpus 1 --steps K --warmup W          Dragon 3840x2160, maxdepth 5, all features, one MI355X
   torchrun ... bench.py --gpus N ...                       the same frame cut into interleaved tiles over N GPUs,
                                                            RCCL gather of the tile buffers + reassembly on rank 0
-  --workload dragon8k | cornell | spheres | grid           the other BASELINE configurations (extra measurements)
+  --workload dragon8k | cornell | spheres | grid           the other benchmark configurations (extra measurements)
 
 A step is one frame: every kernel of the path over the whole image, scene and framebuffer resident in HBM; frames are
 issued round-robin on several streams (frames in flight).  After the timed loop the last frame of every stream is compared
@@ -43,7 +43,7 @@ FP32_PEAK_TFLOPS = 157.3
 NODE_FLOPS, TRI_FLOPS, SPHERE_FLOPS = 24, 60, 120
 
 # name -> (scene text generator in raytracer_amd.workloads, N=1 size, description).  "dragon" is the configuration the
-# metric is quoted on; the others are the remaining BASELINE configurations, selectable for extra measurements.
+# metric is quoted on; the others are the remaining benchmark configurations, selectable for extra measurements.
 WORKLOADS = {
     "dragon": ("dragon", (3840, 2160), "final_scenes/scene7 (Stanford Dragon, 100000 triangles, 1 point light) %dx%d maxdepth 5"),
     "dragon8k": ("dragon", (7680, 4320), "final_scenes/scene7 (Stanford Dragon, 100000 triangles, 1 point light) %dx%d maxdepth 5"),
@@ -254,7 +254,7 @@ def main():
 
     gen, (w1, h1), describe = WORKLOADS[args.workload]
     # the same frame for every N (strong scaling of the configuration the metric is quoted on); the 7680x4320 frame of
-    # BASELINE configs[3] is --workload dragon8k, with an N = 1 run of its own
+    # multi-GPU configuration is --workload dragon8k, with an N = 1 run of its own
     width = args.width or w1
     height = args.height or h1
     trace_mode = _capi.TRACE_FAST if args.trace_mode == "fast" else _capi.TRACE_EXACT

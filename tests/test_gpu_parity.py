@@ -1,7 +1,7 @@
 """GPU: the HIP path, called through the C ABI, against the C oracle and the golden vectors from the reference.
 
 Bars: MIRT_TRACE_EXACT -- bit-exact (ids, float bit patterns of distances and normals, every output byte, ray counts).
-      MIRT_TRACE_FAST  -- BASELINE north_star tolerance: primary nearest-hit ids equal on >= 99.9 % of rays,
+      MIRT_TRACE_FAST  -- the tolerance asked of a non-exact mode: primary nearest-hit ids equal on >= 99.9 % of rays,
                           8-bit channels within +-1 LSB on >= 99.9 % of pixels.
 """
 import numpy as np
