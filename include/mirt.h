@@ -141,9 +141,10 @@ typedef struct mirt_scene_desc {
  * In every mode a ray whose direction or origin is NaN in all three components -- the shadow ray towards a light that lies
  * exactly at the hit point (normalize(0), main.cpp:222), every ray of a camera whose up vector lies along its view -- gets the
  * reference's answer: it passes every box, no triangle, and every sphere, with a NaN distance that counts as a hit
- * (SceneObjects.hpp:35-37).  A ray with SOME components NaN, or with infinite ones -- no frame produces one; mirt_trace_rays
- * can be handed one -- is outside the contract: what the reference answers then depends on the operand order inside its
- * std::min / std::max (AABB.cpp:60-61); the library answers "no hit" (exp/special_rays.py: 6 % of such rays differ). */
+ * (SceneObjects.hpp:35-37).  A ray with SOME components NaN, with infinite ones, or with a direction whose squared length
+ * underflows or overflows -- no frame produces one; mirt_trace_rays can be handed one -- gets the reference's answer there too
+ * (EXACT and REFWALK): that entry point evaluates such a ray exactly as the reference recurses, operand order of its std::min /
+ * std::max included (AABB.cpp:60-61).  Inside a frame only the all-NaN case above is looked for. */
 #define MIRT_TRACE_EXACT 0u
 #define MIRT_TRACE_FAST 1u
 #define MIRT_TRACE_REFWALK 2u

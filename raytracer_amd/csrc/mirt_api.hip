@@ -2509,7 +2509,7 @@ int mirt_trace_rays(mirt_scene* s, uint32_t trace_mode, uint64_t n, const float*
 			const float c = 1e-5f + far * 0x1p-17f * 1.01f / shortest;
 			dsl.cullSlack = std::isfinite(c) ? fmaxf(dsl.cullSlack, c) : __builtin_inff();
 		}
-#define LAUNCH_LIST(M, O) hipLaunchKernelGGL((k_trace_list<M, O>), dim3(grid), dim3(BLOCK), 0, s->stream, dsl, (uint32_t*)s->hookOvf.p, s->ovfStride, n, (const float*)o.p, (const float*)d.p, (int32_t*)id.p, (float*)dist.p, (float*)nrm.p)
+#define LAUNCH_LIST(M, O) hipLaunchKernelGGL((k_trace_list<M, O>), dim3(grid), dim3(BLOCK), 0, s->stream, dsl, (uint32_t*)s->hookOvf.p, s->ovfStride, (MODE_FAST != M && s->wideDepth + 2 <= STACK_MAX) ? 1u : 0u, n, (const float*)o.p, (const float*)d.p, (int32_t*)id.p, (float*)dist.p, (float*)nrm.p)
 		if (mode == MODE_REFWALK) LAUNCH_LIST(MODE_REFWALK, false);
 		else if (mode == MODE_FAST) { if (s->deepBvh) LAUNCH_LIST(MODE_FAST, true); else LAUNCH_LIST(MODE_FAST, false); }
 		else { if (s->deepBvh) LAUNCH_LIST(MODE_EXACT, true); else LAUNCH_LIST(MODE_EXACT, false); }

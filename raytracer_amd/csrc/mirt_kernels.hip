@@ -386,6 +386,95 @@ __device__ __noinline__ bool traverse_ref(const DScene& S, const RayCtx& r, floa
 	}
 }
 
+// ---- rays whose components are not all finite: the reference's recursion as it stands ------------------------------------------
+// What Partition::intersect makes of a NaN or an infinity hangs on details no bounded or ordered walk keeps: std::min and
+// std::max return their FIRST argument when the comparison fails (AABB.cpp:60-61), an Intersection with a NaN distance counts as
+// valid (SceneObjects.hpp:35-37), a leaf keeps the first of two NaN answers (Partition.h:33) and a node the right one
+// (Partition.cpp:47).  So such a ray -- none arises in a frame except the all-NaN ones DScene::nanHit answers; the ray-batch
+// entry points can be handed any -- is evaluated exactly as the reference recurses: every node, left subtree then right, no
+// bound, the comparisons spelled as the reference spells them.  Slow, private arrays, used by the ray-batch kernels only.
+__device__ __forceinline__ float min_std(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float max_std(float a, float b) { return (a < b) ? b : a; }
+__device__ __forceinline__ bool box_valid_ref(f3 o, f3 e, f3 lo, f3 hi) {
+	const float t1 = (lo.x - o.x) / e.x, t2 = (hi.x - o.x) / e.x, t3 = (lo.y - o.y) / e.y, t4 = (hi.y - o.y) / e.y, t5 = (lo.z - o.z) / e.z, t6 = (hi.z - o.z) / e.z;
+	const float tmin = max_std(max_std(min_std(t1, t2), min_std(t3, t4)), min_std(t5, t6)); // :60
+	const float tmax = min_std(min_std(max_std(t1, t2), max_std(t3, t4)), max_std(t5, t6)); // :61
+	if ((double)tmax < 0.0001) return false;   // :65
+	if (tmin > tmax) return false;             // :70
+	const float tResult = tmin < 0.0001f ? tmax : tmin; // :73-78
+	return !isinf(tResult);                    // Partition.cpp:36
+}
+__device__ __noinline__ void traverse_faithful(const DScene& S, f3 o, f3 d, Hit& best) {
+	const RayCtx r = make_ray(o, d);
+	const f3 e = box_dir(r);
+	uint32_t stkNode[STACK_MAX], stkRef[STACK_MAX];
+	float stkDist[STACK_MAX];
+	int sp = 0;
+	// the subtree to evaluate next: its reference and box
+	uint32_t cur = S.rootRef;
+	f3 lo = F3(S.rootMin), hi = F3(S.rootMax);
+	float resDist;   // result of the subtree just evaluated: +inf = no valid intersection (Intersection(), SceneObjects.hpp:33)
+	uint32_t resRef;
+	for (;;) {
+		resDist = __builtin_inff();
+		resRef = REF_NONE;
+		bool descend = false;
+		if (cur != REF_NONE && box_valid_ref(o, e, lo, hi)) {                     // Partition.cpp:36
+			if (cur & REF_LEAF) {                                                  // :39-41, Partition.h:28-39
+				const uint32_t p = cur & ~REF_LEAF, cnt = S.leafs[p];
+				for (uint32_t k = 0; k < cnt; ++k) {
+					const uint32_t pr = S.leafs[p + 1 + k];
+					float dist;
+					f3 dummy;
+					if (pr & PRIM_SPHERE) dist = sphere_hit<false>(r, S.spheres + (size_t)(pr & ~PRIM_SPHERE) * SPHERE_F4, dummy);
+					else dist = tri_hit<MODE_EXACT>(r, S.tris + (size_t)pr * TRI_F4, S.triX + (size_t)pr * 2, __builtin_inff());
+					const bool valid = dist != -1.0f && !isinf(dist);              // (-1: the tests' "no intersection"; a NaN is valid)
+					if (valid && (dist < resDist || isinf(resDist))) { resDist = dist; resRef = pr; } // Partition.h:33
+				}
+			}
+			else descend = true;
+		}
+		if (descend) {                                                             // :42: the left subtree first
+			const float4* nd = S.nodes + (size_t)cur * 4;
+			const float4 q0 = nd[0], q1 = nd[1];
+			stkNode[sp] = cur;
+			stkRef[sp] = 0xfffffffeu; // "left result pending"
+			++sp;
+			cur = __float_as_uint(q0.w);
+			lo = F3(q0); hi = F3(q1);
+			continue;
+		}
+		// a subtree is finished: hand its result to the node above
+		for (;;) {
+			if (sp == 0) { best.dist = resDist; best.ref = resRef; best.pos = 0; return; }
+			const uint32_t node = stkNode[sp - 1];
+			if (stkRef[sp - 1] == 0xfffffffeu) {                                   // that was the left subtree: keep it, do the right one (:43)
+				stkRef[sp - 1] = resRef;
+				stkDist[sp - 1] = resDist;
+				const float4* nd = S.nodes + (size_t)node * 4;
+				const float4 q1 = nd[1], q2 = nd[2], q3 = nd[3];
+				cur = __float_as_uint(q1.w);
+				lo = F3(q2); hi = F3(q3);
+				break;
+			}
+			// both done (:44-52)
+			const float lDist = stkDist[sp - 1];
+			const uint32_t lRef = stkRef[sp - 1];
+			const bool lValid = !isinf(lDist), rValid = !isinf(resDist);
+			--sp;
+			if (!(lValid || rValid)) { resDist = __builtin_inff(); resRef = REF_NONE; }
+			else if ((lValid && !rValid) || lDist <= resDist) { resDist = lDist; resRef = lRef; }
+			// else: the right one, which is in res already
+		}
+	}
+}
+// An ordinary ray: finite origin, and a direction whose squared length neither underflows nor overflows where a primitive test
+// normalises it (Sphere.cpp:60-61 does so in object space: normalize of a vector of squared length 0 is NaN)
+__device__ __forceinline__ bool all_finite(f3 o, f3 d) {
+	const float len2 = dot3(d, d);
+	return fabsf(o.x) < __builtin_inff() && fabsf(o.y) < __builtin_inff() && fabsf(o.z) < __builtin_inff() && len2 >= 1e-30f && len2 <= 1e30f;
+}
+
 // ---- primitive hierarchy + membership check (MODE_EXACT / MODE_FAST) -----------------------------------------------------
 // Slab test for the hierarchy's own boxes: t = b*(1/d) - o*(1/d) as one FMA per plane.  It must never reject a box that
 // contains a point the exact primitive tests can accept.  Its rounding error, mapped back to world space, is below
@@ -1825,7 +1914,7 @@ __global__ __launch_bounds__(BLOCK) void k_png_rows(const uint8_t* __restrict__ 
 
 // ---- narrow seam: closest hit for a list of rays ----------------------------------------------------------------------
 template <int MODE, bool OVF>
-__global__ __launch_bounds__(BLOCK) void k_trace_list(DScene S, uint32_t* ovf, uint32_t ovfStride, uint64_t n, const float* __restrict__ o3, const float* __restrict__ d3,
+__global__ __launch_bounds__(BLOCK) void k_trace_list(DScene S, uint32_t* ovf, uint32_t ovfStride, uint32_t faithful, uint64_t n, const float* __restrict__ o3, const float* __restrict__ d3,
                                                       int32_t* __restrict__ primId, float* __restrict__ dist, float* __restrict__ normal) {
 	__shared__ uint32_t s_stack[MODE == MODE_REFWALK ? 1 : STACK_LDS * BLOCK];
 	LdsStack<OVF> stk;
@@ -1836,7 +1925,8 @@ __global__ __launch_bounds__(BLOCK) void k_trace_list(DScene S, uint32_t* ovf, u
 		const f3 o = F3(o3 + 3 * i), d = F3(d3 + 3 * i);
 		const RayCtx r = make_ray(o, d);
 		Hit h;
-		trace_whole<MODE, OVF>(S, o, d, -1.0f, h, stk);
+		if (faithful && !all_finite(o, d)) traverse_faithful(S, o, d, h); // (faithful: the reference's tree is not deeper than that walk's stack)
+		else trace_whole<MODE, OVF>(S, o, d, -1.0f, h, stk);
 		if (h.ref != REF_NONE) {
 			primId[i] = (int32_t)info_of(S, h.ref).x;
 			dist[i] = h.dist;

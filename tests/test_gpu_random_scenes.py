@@ -173,3 +173,30 @@ def _check(seed, text, tmp_dir, scale=5, fast=True):
             assert np.all(fd[both] <= dist[both])
             if fs.n_prims == len(fs.tri_prim):
                 assert np.array_equal(fi >= 0, ids >= 0)
+
+
+@pytest.mark.parametrize("gen,seed", [(random_scene_text, k) for k in range(12)] + [(hard_scene_text, k) for k in range(6)] + [(nasty_scene_text, k) for k in range(16, 24)])
+def test_rays_with_nan_infinite_and_tiny_components(gen, seed):
+    """mirt_trace_rays with rays no frame produces (the recipe of tests/test_oracle_vs_reference.py, which holds the restatement to
+    the reference on it): such a ray is evaluated as the reference recurses (traverse_faithful), in both modes that promise its answer."""
+    from oracle.bind import CPort
+    from raytracer_amd.device import DeviceScene
+    rng = np.random.default_rng(1000 + seed)
+    specials = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-30, -1e-30, 1e30, 1e38, 3e-6, 1.0, -1.0], np.float32)
+    fs = FlatScene.from_text(gen(seed))
+    n = 600
+    ro = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    rd = rng.normal(size=(n, 3)).astype(np.float32)
+    for k in range(n):
+        for _ in range(int(rng.integers(0, 4))):
+            (rd if rng.random() < 0.5 else ro)[k, rng.integers(0, 3)] = specials[rng.integers(0, len(specials))]
+    rd[::50] = rng.choice(np.array([0.0, -0.0, 1e-30, -1e-30], np.float32), (len(rd[::50]), 3))  # directions without a length
+    ids, dist, _, _ = CPort(fs).trace(ro, rd)
+    nan = np.isnan(dist)
+    with DeviceScene(fs, 0) as s:
+        for mode in (_capi.TRACE_EXACT, _capi.TRACE_REFWALK):
+            if s.query()["tree_wide_depth"] + 2 > 96:
+                continue
+            gi, gd, _ = s.trace_rays(ro, rd, trace_mode=mode)
+            assert np.array_equal(gi, ids), (seed, mode, np.flatnonzero(gi != ids)[:5])
+            assert np.array_equal(np.isnan(gd), nan) and np.array_equal(gd[~nan].view(np.uint32), dist[~nan].view(np.uint32)), (seed, mode)
