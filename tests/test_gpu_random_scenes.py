@@ -120,6 +120,12 @@ def _check(seed, text, tmp_dir, scale=5, fast=True):
                             os.environ.pop(k, None)
                         else:
                             os.environ[k] = v
+            if lib is None and seed % 7 == 0:
+                # frame and PNG file in one call: the file decodes to the same bytes (Renderer.cpp:12-15)
+                from PIL import Image
+                png = os.path.join(tmp_dir, "frame.png")
+                s.render_png(png, W, H)
+                assert np.array_equal(np.asarray(Image.open(png))[..., ::-1], big), (seed, "png")
             if lib is None and seed % 4 == 1:
                 # one rank's share of the frame (every third 16x8 tile): the same share of the oracle's, black elsewhere
                 for first in range(3):
