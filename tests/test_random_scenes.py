@@ -12,7 +12,14 @@ from raytracer_amd.scene import FlatScene
 
 pytestmark = pytest.mark.skipif(not os.path.exists(REF_LIB), reason="reference build oracle/_ref not present")
 
-SEEDS = list(range(36)) + [179, 244, 401, 455, 701]  # (the last five: see tests/test_gpu_random_scenes.py)
+
+
+def _seeds(var, default):
+    """(MIRT_RANDOM_SEEDS / MIRT_HARD_SEEDS / MIRT_NASTY_SEEDS / MIRT_BIG_SEEDS = first:end run another range, as on the GPU side)"""
+    return range(*(int(x) for x in os.environ[var].split(":"))) if os.environ.get(var) else default
+
+
+SEEDS = _seeds("MIRT_RANDOM_SEEDS", list(range(36)) + [179, 244, 401, 455, 701])  # (the last five: see tests/test_gpu_random_scenes.py)
 
 
 @pytest.mark.parametrize("seed", SEEDS)
@@ -20,17 +27,17 @@ def test_loader_and_restatement_match_the_reference_on_a_random_scene(seed, tmp_
     _check(random_scene_text(seed), tmp_path)
 
 
-@pytest.mark.parametrize("seed", list(range(36)) + [138, 192, 433, 559, 601])
+@pytest.mark.parametrize("seed", _seeds("MIRT_HARD_SEEDS", list(range(36)) + [138, 192, 433, 559, 601]))
 def test_loader_and_restatement_match_the_reference_on_a_hard_scene(seed, tmp_path):
     _check(hard_scene_text(seed), tmp_path)
 
 
-@pytest.mark.parametrize("seed", list(range(48)) + [458, 642, 722, 784])
+@pytest.mark.parametrize("seed", _seeds("MIRT_NASTY_SEEDS", list(range(48)) + [458, 642, 722, 784]))
 def test_loader_and_restatement_match_the_reference_on_a_nasty_scene(seed, tmp_path):
     _check(nasty_scene_text(seed), tmp_path)
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", _seeds("MIRT_BIG_SEEDS", range(10)))
 def test_loader_and_restatement_match_the_reference_on_a_big_scene(seed, tmp_path):
     _check(big_scene_text(seed), tmp_path)
 
