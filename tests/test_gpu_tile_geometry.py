@@ -99,3 +99,38 @@ def test_any_tiling_gives_the_whole_frame(seed, flat_scenes):
         assert np.array_equal(got, want), (w, h, tw, th, stride)
         hip.rt.hipFree(gathered)
         hip.rt.hipFree(image)
+
+
+def test_more_frame_geometries_than_a_scene_keeps_lists_for(flat_scenes):
+    """A scene keeps the visible-block lists of the last 32 frame geometries and starts over at the 33rd.  Forty sizes on one
+    handle, their frames in flight on four streams while the lists are thrown away and made again, each held to the same
+    size rendered alone afterwards."""
+    from raytracer_amd.device import DeviceScene
+    hip = _Hip()
+    hip.rt.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.rt.hipStreamDestroy.argtypes = [C.c_void_p]
+    hip.rt.hipStreamSynchronize.argtypes = [C.c_void_p]
+    streams = []
+    for _ in range(4):
+        st = C.c_void_p()
+        assert hip.rt.hipStreamCreate(C.byref(st)) == 0
+        streams.append(st.value)
+    sizes = [(200 + 24 * i, 120 + 8 * (i % 7) + i) for i in range(40)]
+    with DeviceScene(flat_scenes("scene7"), 0) as s:
+        bufs = []
+        for i, (w, h) in enumerate(sizes):
+            p = _capi.make_params(w, h)
+            b = hip.alloc(w * h * 3)
+            s.render_device(p, b, w * h * 3, streams[i % 4])
+            bufs.append(b)
+        for st in streams:
+            assert hip.rt.hipStreamSynchronize(st) == 0
+        for (w, h), b in zip(sizes, bufs):
+            got = hip.to_host(b, w * h * 3).reshape(h, w, 3)
+            want, _ = s.render(w, h)
+            assert want.any() and np.array_equal(got, want), (w, h)
+            hip.rt.hipFree(b)
+        for st in streams:
+            s.release_stream(st)
+    for st in streams:
+        hip.rt.hipStreamDestroy(st)
