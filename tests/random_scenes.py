@@ -517,3 +517,31 @@ def mutated_scene_text(seed):
     column 0, stray stack commands and short argument lists.  (Lines with integer arguments are left alone: an index out of
     range is undefined behaviour in the reference.)"""
     return mutate(random_scene_text(seed % 48), np.random.default_rng(900000 + seed))
+
+
+def many_lights_scene_text(n_lights, seed=0):
+    """A few spheres, a floor and a mirror under n_lights lights of both kinds, some of them inside objects or below the floor:
+    the light loop of main.cpp:208-223 at lengths a counter per hit, a bit mask per hit or a byte per light could trip over
+    (31, 32, 33, 63, 64, 65, 255, 256, 257 ...)."""
+    rng = np.random.default_rng(7000 + 31 * n_lights + seed)
+    out = ["size %d %d" % (int(rng.integers(40, 90)), int(rng.integers(30, 60))), "maxdepth %d" % int(rng.integers(1, 4)),
+           "camera 0 1.5 6 0 0.3 0 0 1 0 45"]
+    if seed % 2:
+        out.append("attenuation 1 0.1 0.02")
+    for i in range(n_lights):
+        col = _vec(rng.uniform(0.2, 1.0, 3) * (3.0 / max(n_lights, 3)))
+        if rng.random() < 0.7:
+            out.append("point %s %s" % (_vec(rng.uniform(-4, 4, 3) + np.array([0, 2.5, 1])), col))
+        else:
+            out.append("directional %s %s" % (_vec(rng.uniform(-1, 1, 3) + np.array([0, 1.2, 0.4])), col))
+    out += ["maxverts 8", "vertex -5 -0.5 -5", "vertex 5 -0.5 -5", "vertex 5 -0.5 5", "vertex -5 -0.5 5",
+            "vertex -3 -0.5 -3", "vertex 3 -0.5 -3", "vertex 3 3 -3", "vertex -3 3 -3"]
+    out += ["ambient 0.02 0.02 0.03", "diffuse 0.6 0.6 0.5", "specular 0.2 0.2 0.2", "shininess 30", "tri 0 2 1", "tri 0 3 2",
+            "diffuse 0.1 0.1 0.1", "specular 0.8 0.8 0.8", "shininess 100", "tri 4 5 6", "tri 4 6 7"]
+    for _ in range(int(rng.integers(2, 6))):
+        out += ["diffuse %s" % _vec(rng.uniform(0.1, 0.9, 3)), "specular %s" % _vec(rng.uniform(0, 0.6, 3)), "shininess %d" % int(rng.choice([5, 20, 80])),
+                "sphere %s %s" % (_vec(rng.uniform(-2, 2, 3) + np.array([0, 0.6, 0])), _f(rng.uniform(0.3, 0.9)))]
+    return "\n".join(out) + "\n"
+
+
+MANY_LIGHTS = [31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 700]

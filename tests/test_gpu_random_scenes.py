@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from random_scenes import big_scene_text, hard_scene_text, nasty_scene_text, random_scene_text
+from random_scenes import MANY_LIGHTS, big_scene_text, hard_scene_text, many_lights_scene_text, nasty_scene_text, random_scene_text
 from raytracer_amd import _capi
 from raytracer_amd.scene import FlatScene
 
@@ -50,6 +50,12 @@ NASTY_SEEDS = (range(*(int(x) for x in os.environ["MIRT_NASTY_SEEDS"].split(":")
 @pytest.mark.parametrize("seed", NASTY_SEEDS)
 def test_nasty_scene_matches_the_oracle(seed, tmp_path):
     _check(seed, nasty_scene_text(seed), str(tmp_path), scale=2, fast=False)
+
+
+@pytest.mark.parametrize("n_lights", MANY_LIGHTS)
+def test_many_lights(n_lights, tmp_path):
+    """31 to 700 lights: the light loop at lengths that a mask, a counter or a byte per light could trip over."""
+    _check(n_lights, many_lights_scene_text(n_lights, n_lights % 3), str(tmp_path), scale=2, fast=True)
 
 
 BIG_SEEDS = range(*(int(x) for x in os.environ["MIRT_BIG_SEEDS"].split(":"))) if os.environ.get("MIRT_BIG_SEEDS") else range(10)

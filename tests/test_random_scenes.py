@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle.bind import CPort, REF_LIB, RefOracle
-from random_scenes import big_scene_text, hard_scene_text, mutated_scene_text, nasty_scene_text, random_scene_text
+from random_scenes import MANY_LIGHTS, big_scene_text, hard_scene_text, many_lights_scene_text, mutated_scene_text, nasty_scene_text, random_scene_text
 from raytracer_amd.scene import FlatScene
 
 pytestmark = pytest.mark.skipif(not os.path.exists(REF_LIB), reason="reference build oracle/_ref not present")
@@ -40,6 +40,11 @@ def test_loader_and_restatement_match_the_reference_on_a_nasty_scene(seed, tmp_p
 @pytest.mark.parametrize("seed", _seeds("MIRT_BIG_SEEDS", range(10)))
 def test_loader_and_restatement_match_the_reference_on_a_big_scene(seed, tmp_path):
     _check(big_scene_text(seed), tmp_path)
+
+
+@pytest.mark.parametrize("n_lights", MANY_LIGHTS)
+def test_loader_and_restatement_match_the_reference_under_many_lights(n_lights, tmp_path):
+    _check(many_lights_scene_text(n_lights, n_lights % 3), tmp_path)
 
 
 def _check(text, tmp_path):
