@@ -71,3 +71,25 @@ def test_maxdepth_below_zero_at_a_size_that_takes_the_staged_copy():
         _, st = s.render(out=img)
         assert not img.any()
         assert st["primary_rays"] == 1920 * 1080 and st["shadow_rays"] == 0 and st["reflection_rays"] == 0
+
+
+@pytest.mark.parametrize("size", [(65536, 1), (1, 65536), (65535, 7), (9, 16385)])
+def test_images_one_pixel_wide_or_high_at_the_largest_size(size, flat_scenes):
+    """main.cpp:137-163 loops over whatever width and height the scene names.  The library takes up to 65536 either way: a row or a
+    column of that length, whole and as one rank's share of 64x8 tiles, against the C oracle; one pixel more is refused."""
+    from oracle.bind import CPort
+    from raytracer_amd.device import DeviceScene, MirtError
+    w, h = size
+    fs = flat_scenes("scene6")
+    want, wst = CPort(fs).render(w, h)
+    with DeviceScene(fs, 0) as s:
+        for mode in (_capi.TRACE_EXACT, _capi.TRACE_REFWALK):
+            img, st = s.render(w, h, trace_mode=mode)
+            assert np.array_equal(img, want), (size, mode)
+            assert [st[k] for k in ("primary_rays", "shadow_rays", "reflection_rays")] == [wst[k] for k in ("primary_rays", "shadow_rays", "reflection_rays")]
+        part, _ = s.render(w, h, tile_w=64, tile_h=8, first_tile=1, tile_stride=3)
+        ty, tx = np.meshgrid(np.arange(h) // 8, np.arange(w) // 64, indexing="ij")
+        mine = (ty * ((w + 63) // 64) + tx) % 3 == 1
+        assert np.array_equal(part[mine], want[mine]) and not part[~mine].any()
+        with pytest.raises(MirtError, match="not supported"):
+            s.render(65537, 1)
