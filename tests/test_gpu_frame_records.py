@@ -54,3 +54,26 @@ def test_big_frames_equal_the_slot_indexed_ones(size, tiles, flat_scenes, monkey
             got, st = s.render(w, h, **tiles)
             assert want.any() and np.array_equal(got, want), "%d bytes differ" % int((got != want).sum())
             assert {**st, "device_ms": 0} == {**wst, "device_ms": 0}
+
+
+def test_a_frame_of_more_than_2_27_pixel_slots(flat_scenes):
+    """From 2^27 slots on a slot number no longer fits beside the path's depth in one word and k_frame keeps its paths in hit
+    records by itself.  16400x8200 (134.5 M slots, 403 MB of image) against the same frame rendered as two ranks' shares of half
+    as many slots each, which take the slot-indexed kernel.  (exp/huge_frame.py does the same at 44000x44000 -- 1.9 G slots,
+    byte offsets beyond 32 bits -- against sixteen shares: equal, 17.6 Grays/s.)"""
+    from raytracer_amd.device import DeviceScene
+    w, h = 16400, 8200
+    assert w * h >= 1 << 27
+    with DeviceScene(flat_scenes("scene7"), 0) as s:
+        whole = np.zeros((h, w, 3), np.uint8)
+        _, st = s.render(w, h, out=whole)
+        acc = np.zeros((h, w, 3), np.uint8)
+        tot = dict.fromkeys(("primary_rays", "shadow_rays", "reflection_rays"), 0)
+        for r in range(2):
+            part = np.zeros((h, w, 3), np.uint8)
+            _, ps = s.render(w, h, out=part, tile_w=1024, tile_h=8, first_tile=r, tile_stride=2)
+            acc |= part
+            for k in tot:
+                tot[k] += ps[k]
+        assert whole.any() and np.array_equal(acc, whole)
+        assert tot == {k: st[k] for k in tot}
