@@ -38,6 +38,7 @@ if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 16:
     os.environ["GPU_MAX_HW_QUEUES"] = "16"
 
 HBM_PEAK_GBS = 8000.0
+RANDOM_READ_REQUESTS_G = 56.0  # memory-side read requests per ns at best (random 64- or 128-byte records over 1 GiB, measured)
 NODE_BYTES, TRI_BYTES, SPHERE_BYTES, RAY_STATE_BYTES = 32, 40, 116, 32
 FP32_PEAK_TFLOPS = 157.3
 NODE_FLOPS, TRI_FLOPS, SPHERE_FLOPS = 24, 60, 120
@@ -192,6 +193,14 @@ def roofline(scene, flat, args, width, height, trace_mode, rays, vis, srays, ker
     if traffic:
         out["hbm"] = {"bytes_per_frame": traffic, "GBs_per_step": traffic / step_s / 1e9, "utilisation_per_step": traffic / step_s / 1e9 / HBM_PEAK_GBS,
                       "GBs_alone": traffic / (ms_alone * 1e-3) / 1e9, "l2_hit": pmc.get("l2_hit")}
+        if pmc.get("fetch_bytes_per_frame_x2_corrected"):
+            # Beyond the caches the memory system is bound by read REQUESTS, not bytes: independent random reads of 64-byte and
+            # of 128-byte records both run at one request per record and 56 G requests/s (exp/ubench/random_gather.hip, counters
+            # beside the timings in profiles/r03/random_gather.txt), and FETCH_SIZE tallies every request at 64 B.
+            req = pmc["fetch_bytes_per_frame_x2_corrected"] / 128.0
+            out["hbm"]["read_requests"] = {"per_frame": req, "G_per_s_per_step": req / step_s / 1e9, "G_per_s_alone": req / (ms_alone * 1e-3) / 1e9,
+                                           "ceiling_G_per_s": RANDOM_READ_REQUESTS_G, "frac_per_step": req / step_s / 1e9 / RANDOM_READ_REQUESTS_G,
+                                           "note": "memory-side read requests (FETCH_SIZE / 64 B) against the measured rate of independent random reads"}
     c = device_walk_counts(flat, scene.device, width, height, trace_mode)
     if c:
         hits = c["hits"]
