@@ -1228,6 +1228,9 @@ int enqueue_frame(mirt_scene* s, FrameCtx* c, const mirt_render_params* p, const
 	// time is not lost: measured on the Stanford dragon at 3840x2160, frames without queued clears run 14.00 against 14.10
 	// Grays/s over 80 frames and 13.0 against 13.7 over 20 (a burst of frames that all start at the same moment also end
 	// together; the clears in front of them spread their starts).  So the queued clears stay the default.
+	// (Measured again with the visible-block lists, three interleaved runs: 13.0-13.5 against 14.6-14.9 Grays/s over 20 frames,
+	// 14.1 against 15.4 over 80, a frame alone 1.56-1.64 against 1.43-1.45 ms -- a frame that clears for itself has to visit
+	// every block of the image, the 57 % that see nothing included.)
 	const char* cikEnv = getenv("MIRT_CLEAR_IN_KERNEL"); // (read per frame: tests switch it)
 	const bool clearInKernel = cikEnv && *cikEnv == '1';
 	uint32_t* const ctrBase = (uint32_t*)mem[WS_COUNTERS];
