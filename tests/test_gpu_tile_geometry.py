@@ -56,7 +56,8 @@ class _Hip:
         return out
 
 
-# (MIRT_TILE_SEEDS=first:end runs another range; 1500 were run once, all equal)
+# (MIRT_TILE_SEEDS=first:end runs another range; 1500 were run once, all equal, and 400 each with the frame run as per-depth
+# launches (MIRT_SINGLE_LAUNCH=0), with hit records (MIRT_FRAME_RECORDS=1) and with forced shared walks (MIRT_SHARE=1))
 SEEDS = range(*(int(x) for x in os.environ["MIRT_TILE_SEEDS"].split(":"))) if os.environ.get("MIRT_TILE_SEEDS") else range(36)
 
 
